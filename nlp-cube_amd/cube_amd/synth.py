@@ -1,0 +1,228 @@
+"""Deterministic synthetic models and corpora.
+
+No released checkpoint, treebank or embedding model can be fetched offline, so
+every test, fixture and benchmark in this repo runs on a synthetic vocabulary,
+a random-init `state_dict` with the reference's key names and shapes
+(reference: cube/networks/parser.py:23-95, tagger.py:22-67, modules.py:424-448,
+564-579) and synthetic CoNLL-U documents.  Everything is generated from
+`numpy.random.default_rng(seed)` only, so the same objects can be re-created
+bit-identically in the build container (where the reference is loaded with the
+dict) and on the GPU box (where only this repo exists).
+"""
+import numpy as np
+import torch
+
+from cube_amd.io_utils.encodings import Encodings
+from cube_amd.io_utils.objects import Document, Sentence, Word
+
+# en flavours of the 3.0 'en' model (reference: scripts/train/2.5/language/en.yaml:7-22)
+EN_LANGUAGE_CODES = ["en_esl", "en_pud", "en_gum", "en_ewt", "en_lines", "en_partut"]
+EN_LANGUAGE_MAP = {"en": "en_ewt"}
+
+
+def _symbols(n_chars):
+    """n_chars-3 printable non-space symbols: lower-case letters first, then digits,
+    punctuation, then letters from other scripts that have distinct upper/lower forms."""
+    pool = [chr(c) for c in range(ord("a"), ord("z") + 1)] + [str(d) for d in range(10)]
+    pool += list(".,;:!?-'\"()[]/&%$#@*+=<>_~^|\\{}`")
+    pool += [chr(c) for c in range(0x3b1, 0x3ca) if chr(c).upper() != chr(c)]  # greek lower
+    pool += [chr(c) for c in range(0x430, 0x450)]  # cyrillic lower
+    out = []
+    for s in pool:
+        if s not in out and s != " ":
+            out.append(s)
+    if len(out) < n_chars - 3:
+        raise ValueError("symbol pool too small")
+    return out[: n_chars - 3]
+
+
+def make_encodings(n_chars=100, n_words=20002, n_upos=19, n_xpos=52, n_attrs=240, n_labels=52, num_langs=6):
+    """Synthetic vocabulary with the sizes of SURVEY.md §8d (all counts include <PAD>/<UNK>)."""
+    chars = _symbols(n_chars)
+    letters = [c for c in chars if c.upper() != c.lower()]
+    rng = np.random.default_rng(20240)
+    seen = set()
+    words = []
+    while len(words) < n_words - 2:  # lower-case strings, length 1+Poisson(4) clipped to [1,16]
+        wl = int(np.clip(1 + rng.poisson(4), 1, 16))
+        s = "".join(rng.choice(letters, wl))
+        if s not in seen:
+            seen.add(s)
+            words.append(s)
+    return Encodings.from_lists(chars, words,
+                                ["U%d" % i for i in range(n_upos - 2)],
+                                ["X%d" % i for i in range(n_xpos - 2)],
+                                ["A%d=v" % i for i in range(n_attrs - 2)],
+                                ["dep%d" % i for i in range(n_labels - 2)], num_langs)
+
+
+# ------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+class _Init:
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+
+    def normal(self, shape, std=1.0):
+        return _t(self.rng.standard_normal(shape) * std)
+
+    def uniform(self, shape, lo, hi):
+        return _t(self.rng.uniform(lo, hi, shape))
+
+    def xavier(self, shape, gain=1.0):
+        # shape = [out, in] or [out, in, k]
+        rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+        fan_in, fan_out = shape[1] * rf, shape[0] * rf
+        return self.normal(shape, gain * np.sqrt(2.0 / (fan_in + fan_out)))
+
+    def emb(self, rows, dim, padding_idx=None):
+        w = self.normal((rows, dim))
+        if padding_idx is not None:
+            w[padding_idx] = 0
+        return w
+
+    def linear(self, sd, prefix, n_out, n_in, xavier=True):
+        b = 1.0 / np.sqrt(n_in)
+        sd[prefix + ".weight"] = self.xavier((n_out, n_in)) if xavier else self.uniform((n_out, n_in), -b, b)
+        sd[prefix + ".bias"] = self.uniform((n_out,), -b, b)
+
+    def gated_conv_stack(self, sd, prefix, n_layers, first_in, next_in, filters):
+        cin = first_in
+        for l in range(n_layers):
+            p = "%s.%d" % (prefix, l)
+            sd[p + ".0.conv.weight"] = self.xavier((filters, cin, 5), gain=5.0 / 3.0)
+            b = 1.0 / np.sqrt(cin * 5)
+            sd[p + ".0.conv.bias"] = self.uniform((filters,), -b, b)
+            # BatchNorm1d in eval mode: non-trivial statistics so that folding is exercised
+            sd[p + ".1.weight"] = self.uniform((filters,), 0.8, 1.2)
+            sd[p + ".1.bias"] = self.normal((filters,), 0.1)
+            sd[p + ".1.running_mean"] = self.normal((filters,), 0.1)
+            sd[p + ".1.running_var"] = self.uniform((filters,), 0.5, 1.5)
+            sd[p + ".1.num_batches_tracked"] = torch.tensor(100, dtype=torch.long)
+            cin = next_in
+
+
+def _common_front(ini, sd, config, enc, ext_word_emb, wordgram_chars):
+    half_c = config.char_filter_size // 2
+    half_w = config.cnn_filter // 2
+    G = enc.num_langs
+    # WordGram(num_chars, num_langs=G+1): tables num_chars+3 / G+2 / 4   (modules.py:430-432)
+    sd["_word_net._lang_emb.weight"] = ini.emb(G + 2, config.lang_emb_size, 0)
+    sd["_word_net._tok_emb.weight"] = ini.emb(wordgram_chars + 3, config.char_emb_size, 0)
+    sd["_word_net._case_emb.weight"] = ini.emb(4, 32, 0)
+    ini.gated_conv_stack(sd, "_word_net._convolutions_char", config.char_layers,
+                         config.char_emb_size + 32 + config.lang_emb_size, half_c + config.lang_emb_size,
+                         config.char_filter_size)
+    ini.linear(sd, "_word_net._pre_out.linear_layer", half_c, half_c)
+    sd["_zero_emb.weight"] = ini.emb(1, half_c)
+    for i, e in enumerate(ext_word_emb):
+        ini.linear(sd, "_ext_proj.%d._h1.linear_layer" % i, 500, e)
+        ini.linear(sd, "_ext_proj.%d._h2.linear_layer" % i, config.external_proj_size, 500)
+    sd["_word_emb.weight"] = ini.emb(len(enc.word2int), config.word_emb_size, 0)
+    sd["_lang_emb.weight"] = ini.emb(G + 1, config.lang_emb_size, 0)
+    first_in = half_c + config.lang_emb_size + config.word_emb_size + config.external_proj_size
+    ini.gated_conv_stack(sd, "_convs", config.cnn_layers, first_in, half_w + config.lang_emb_size, config.cnn_filter)
+    for name, n in (("_aupos", len(enc.upos2int)), ("_axpos", len(enc.xpos2int)), ("_aattrs", len(enc.attrs2int))):
+        ini.linear(sd, name + ".linear_layer", n, half_c + config.lang_emb_size)
+    return half_c, half_w, first_in
+
+
+def make_parser_state_dict(config, enc, ext_word_emb, seed=1234):
+    """Random `state_dict` for `Parser(config, enc, ext_word_emb=...)`; key names/shapes as
+    SURVEY.md §8a-W.  The biaffine weights, zero-initialised by the reference
+    (modules.py:541-542,555-556), are randomised so that arc/label parity is not vacuous."""
+    if not isinstance(ext_word_emb, (list, tuple)):
+        ext_word_emb = [ext_word_emb]
+    ini = _Init(seed)
+    sd = {}
+    L = config.lang_emb_size
+    half_c, half_w, first_in = _common_front(ini, sd, config, enc, ext_word_emb, len(enc.char2int) - 2)
+    n_u, n_x, n_a, n_l = len(enc.upos2int), len(enc.xpos2int), len(enc.attrs2int), len(enc.label2int)
+    ini.linear(sd, "_pre_morpho.linear_layer", half_w, half_w + L)
+    ini.linear(sd, "_upos.linear_layer", n_u, half_w + L)
+    ini.linear(sd, "_attrs.linear_layer", n_a, 64 + half_w + L)
+    ini.linear(sd, "_xpos.linear_layer", n_x, 64 + half_w + L)
+    sd["_upos_emb.weight"] = ini.emb(n_u, 64)
+    H = config.rnn_size
+    b = 1.0 / np.sqrt(H)
+    for l in range(config.rnn_layers):
+        nin = half_w + L + config.external_proj_size if l == 0 else 2 * H
+        for suffix in ("", "_reverse"):
+            sd["_rnn.weight_ih_l%d%s" % (l, suffix)] = ini.uniform((4 * H, nin), -b, b)
+            sd["_rnn.weight_hh_l%d%s" % (l, suffix)] = ini.uniform((4 * H, H), -b, b)
+            sd["_rnn.bias_ih_l%d%s" % (l, suffix)] = ini.uniform((4 * H,), -b, b)
+            sd["_rnn.bias_hh_l%d%s" % (l, suffix)] = ini.uniform((4 * H,), -b, b)
+    ini.linear(sd, "_pre_out.linear_layer", config.pre_parser_size, 2 * H + L)
+    for name, hid, n_out in (("_head", config.head_size, 1), ("_label", config.label_size, n_l)):
+        ini.linear(sd, name + ".W1", hid, config.pre_parser_size, xavier=False)
+        ini.linear(sd, name + ".W2", hid, config.pre_parser_size, xavier=False)
+    hs, ls = config.head_size + 1, config.label_size + 1
+    sd["_head.scorer.W_bilin.weight"] = ini.normal((hs, hs, 1), 0.1)
+    sd["_head.scorer.W_bilin.bias"] = ini.normal((1,), 0.1)
+    sd["_label.scorer.W_bilin.weight"] = ini.normal((n_l, ls, ls), 0.05)
+    sd["_label.scorer.W_bilin.bias"] = ini.normal((n_l,), 0.1)
+    sd["_r_emb.weight"] = ini.emb(1, first_in)
+    return sd
+
+
+def make_tagger_state_dict(config, enc, ext_word_emb, seed=4321):
+    """Random `state_dict` for the stand-alone `Tagger` (reference: tagger.py:22-67)."""
+    if not isinstance(ext_word_emb, (list, tuple)):
+        ext_word_emb = [ext_word_emb]
+    ini = _Init(seed)
+    sd = {}
+    L = config.lang_emb_size
+    half_c, half_w, first_in = _common_front(ini, sd, config, enc, ext_word_emb, len(enc.char2int))
+    n_u, n_x, n_a = len(enc.upos2int), len(enc.xpos2int), len(enc.attrs2int)
+    ini.linear(sd, "_upos.linear_layer", n_u, half_w + L)
+    sd["_upos_emb.weight"] = ini.emb(n_u, 64)
+    ini.linear(sd, "_xpos.linear_layer", n_x, 64 + L + half_w)
+    ini.linear(sd, "_attrs.linear_layer", n_a, 64 + L + half_w)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------
+# corpora
+# ------------------------------------------------------------------------------------------
+def make_document(enc, sent_lens, seed=0, ext_word_emb=(300,), lang_ids=None, unk_rate=0.3,
+                  max_word_len=16, emb_dtype=np.float32):
+    """Synthetic tokenised document: word length 1+Poisson(4) clipped to
+    [1,max_word_len]; characters uniform over the known symbols; 15 % capitalised, 10 %
+    symbol-only, `unk_rate` of the words out of vocabulary (the rest are vocabulary
+    entries, whose spelling 'w<i>' then also fixes their characters); `word.emb` = K
+    vectors ~ N(0,1) in float32.  `lang_ids` = one id per sentence (default: uniform)."""
+    rng = np.random.default_rng(seed)
+    chars = [c for c, i in enc.char2int.items() if i >= 3]
+    letters = [c for c in chars if c.upper() != c.lower()]
+    symbols = [c for c in chars if c.upper() == c.lower()]
+    vocab = [w for w, i in enc.word2int.items() if i >= 2]
+    doc = Document()
+    for si, n in enumerate(sent_lens):
+        rows = []
+        for wi in range(int(n)):
+            u = rng.random()
+            if u < unk_rate or not vocab:
+                wl = int(np.clip(1 + rng.poisson(4), 1, max_word_len))
+                kind = rng.random()
+                if kind < 0.10:
+                    s = "".join(rng.choice(symbols, wl))
+                else:
+                    s = "".join(rng.choice(letters, wl))
+                    if kind < 0.25:
+                        s = s[0].upper() + s[1:]
+                    elif kind < 0.28:
+                        s = s.upper()
+            else:
+                s = vocab[int(rng.integers(len(vocab)))]
+                if rng.random() < 0.15:
+                    s = s[0].upper() + s[1:]
+            w = Word(wi + 1, s, "_", "_", "_", "_", 0, "_", "_", "_")
+            w.emb = [rng.standard_normal(e).astype(emb_dtype) for e in ext_word_emb]
+            rows.append(w)
+        lang = int(rng.integers(enc.num_langs)) if lang_ids is None else int(lang_ids[si])
+        doc.sentences.append(Sentence(sequence=rows, lang_id=lang))
+    return doc

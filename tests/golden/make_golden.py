@@ -1,0 +1,213 @@
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are plain
+arrays/strings (inputs are re-created from seeds by cube_amd.synth, outputs are stored).
+Nothing of the reference's code is stored.  The reference needs two packages that are not
+installed here (pytorch_lightning, fasttext); it only uses `pl.LightningModule` as an
+nn.Module base, `pl.callbacks.Callback` as a base class and `self._device`, so two in-process
+stand-in modules are registered before the import.
+
+    python tests/golden/make_golden.py            # writes tests/golden/g*.npz / *.txt
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "nlp-cube_amd"))
+sys.path.insert(0, ROOT)
+
+
+def _import_reference():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self._device = torch.device("cpu")
+
+    pl.LightningModule = LightningModule
+    cb = types.ModuleType("pytorch_lightning.callbacks")
+    cb.Callback = object
+    pl.callbacks = cb
+    sys.modules["pytorch_lightning"] = pl
+    sys.modules["pytorch_lightning.callbacks"] = cb
+    ft = types.ModuleType("fasttext")
+    ftu = types.ModuleType("fasttext.util")
+    ft.util = ftu
+    sys.modules["fasttext"] = ft
+    sys.modules["fasttext.util"] = ftu
+    sys.path.insert(0, "/root/reference")
+    from cube.networks.parser import Parser
+    from cube.networks.tagger import Tagger
+    from cube.networks.utils import MorphoCollate, ChuLiuEdmondsDecoder
+    from cube.io_utils.objects import Document, Sentence, Word
+    from cube.io_utils.encodings import Encodings
+    from cube.io_utils.config import ParserConfig, TaggerConfig
+    return dict(Parser=Parser, Tagger=Tagger, MorphoCollate=MorphoCollate, CLE=ChuLiuEdmondsDecoder,
+                Document=Document, Sentence=Sentence, Word=Word, Encodings=Encodings,
+                ParserConfig=ParserConfig, TaggerConfig=TaggerConfig)
+
+
+REF = _import_reference()
+
+from cube_amd import synth  # noqa: E402
+from cube_amd.io_utils.config import ParserConfig, TaggerConfig  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def ref_encodings(enc, tmp="/tmp/_golden.encodings"):
+    enc.save(tmp)
+    e = REF["Encodings"]()
+    e.load(tmp)
+    return e
+
+
+def ref_document(doc):
+    """our synthetic Document -> reference Document (same words / emb / lang_id)."""
+    out = REF["Document"]()
+    for s in doc.sentences:
+        rows = []
+        for w in s.words:
+            r = REF["Word"](w.index, w.word, w.lemma, w.upos, w.xpos, w.attrs, w.head, w.label, w.deps, w.space_after)
+            r.emb = w.emb
+            rows.append(r)
+        out.sentences.append(REF["Sentence"](sequence=rows, lang_id=s.lang_id))
+    return out
+
+
+def ref_config(cls_name, cfg):
+    c = REF[cls_name]()
+    for k, v in cfg.__dict__.items():
+        if not k.startswith("_"):
+            setattr(c, k, v)
+    return c
+
+
+def build_ref_parser(case):
+    cfg, enc, sd = cases.parser_model(case)
+    p = REF["Parser"](ref_config("ParserConfig", cfg), ref_encodings(enc), language_codes=synth.EN_LANGUAGE_CODES,
+                      ext_word_emb=list(case["ext"]))
+    missing = p.load_state_dict(sd, strict=True)
+    p.eval()
+    return p, cfg, enc, sd
+
+
+def g1_collate():
+    case = cases.TINY
+    _, enc, _ = cases.parser_model(case)
+    doc = cases.document(case, enc, "g1")
+    col = REF["MorphoCollate"](ref_encodings(enc))
+    out = col.collate_fn(ref_document(doc).sentences)
+    save = {k: v.numpy() for k, v in out.items() if isinstance(v, torch.Tensor) and not k.startswith("y_")}
+    for i, e in enumerate(out["x_word_embeddings"]):
+        save["emb%d" % i] = e.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_collate.npz"), **save)
+    print("g1", {k: v.shape for k, v in save.items()})
+
+
+def forward_fixture(name, case, doc_keys, with_weights):
+    p, cfg, enc, sd = build_ref_parser(case)
+    col = REF["MorphoCollate"](ref_encodings(enc))
+    dec = REF["CLE"]()
+    save = {}
+    for dk in doc_keys:
+        doc = cases.document(case, enc, dk)
+        batch = col.collate_fn(ref_document(doc).sentences)
+        del batch["y_upos"]
+        inter = {}
+        hooks = [p._word_net.register_forward_hook(lambda m, i, o: inter.__setitem__("char_emb_packed", o)),
+                 p._rnn.register_forward_hook(lambda m, i, o: inter.__setitem__("rnn_out", o[0]))]
+        with torch.no_grad():
+            att, labels, upos, xpos, attrs, aupos, axpos, aattrs = p.forward(batch)
+            sl = batch["x_sent_len"].numpy()
+            probs = torch.softmax(att, dim=-1).numpy()
+            heads = dec.decode(probs, sl)
+            lab = p._get_labels(labels, heads)
+        for h in hooks:
+            h.remove()
+        hp = np.zeros((len(heads), att.shape[1]), dtype=np.int64)
+        for b, h in enumerate(heads):
+            hp[b, :len(h)] = h
+        rec = dict(arc_logits=att, pre_parsing=labels, upos=upos, xpos=xpos, attrs=attrs, aupos=aupos, axpos=axpos,
+                   aattrs=aattrs, label_logits=lab, char_emb_packed=inter["char_emb_packed"], rnn_out=inter["rnn_out"])
+        for k, v in rec.items():
+            save["%s/%s" % (dk, k)] = v.numpy().astype(np.float32)
+        save["%s/heads" % dk] = hp
+        save["%s/sent_len" % dk] = sl
+    np.savez_compressed(os.path.join(HERE, name), **save)
+    print(name, len(save), "arrays")
+
+
+def g4_mst():
+    dec = REF["CLE"]()
+    save = {}
+    for key, (probs, lens) in cases.mst_cases().items():
+        try:
+            heads = dec.decode(probs.copy(), lens)
+            hp = np.zeros((len(heads), probs.shape[1]), dtype=np.int64)
+            for b, h in enumerate(heads):
+                hp[b, :len(h)] = h
+            save[key] = hp
+        except AssertionError:
+            save[key] = np.array([-1])
+    if os.path.exists("debug.log"):
+        os.remove("debug.log")
+    np.savez_compressed(os.path.join(HERE, "g4_mst.npz"), **save)
+    print("g4", len(save), "cases")
+
+
+def g6_process():
+    for case, tag in ((cases.TINY, "tiny"), (cases.FULL, "full")):
+        p, cfg, enc, sd = build_ref_parser(case)
+        col = REF["MorphoCollate"](ref_encodings(enc))
+        for bs in (4, 32):
+            doc = ref_document(cases.document(case, enc, "g6"))
+            p.process(doc, col, batch_size=bs, num_workers=0)
+            with open(os.path.join(HERE, "g6_process_%s_bs%d.conllu" % (tag, bs)), "w", encoding="utf-8") as f:
+                f.write(str(doc))
+            print("g6", tag, bs)
+
+
+def g7_tagger():
+    save = {}
+    for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
+        cfg, enc, sd = cases.tagger_model(case)
+        t = REF["Tagger"](ref_config("TaggerConfig", cfg), ref_encodings(enc), language_codes=synth.EN_LANGUAGE_CODES,
+                          ext_word_emb=list(case["ext"]))
+        t.load_state_dict(sd, strict=True)
+        t.eval()
+        col = REF["MorphoCollate"](ref_encodings(enc))
+        for dk in ("ragged",):
+            doc = cases.document(case, enc, dk)
+            batch = col.collate_fn(ref_document(doc).sentences)
+            del batch["y_upos"]
+            with torch.no_grad():
+                outs = t.forward(batch)
+            for k, v in zip(("upos", "xpos", "attrs", "aupos", "axpos", "aattrs"), outs):
+                save["%s/%s/%s" % (tag, dk, k)] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "g7_tagger.npz"), **save)
+    print("g7", len(save), "arrays")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    if "g1" in which:
+        g1_collate()
+    if "g2" in which:
+        forward_fixture("g2_forward_tiny.npz", cases.TINY, ("equal", "ragged", "single"), True)
+    if "g3" in which:
+        forward_fixture("g3_forward_full.npz", cases.FULL, ("full_8x32", "full_2x128", "ragged"), False)
+    if "g4" in which:
+        g4_mst()
+    if "g6" in which:
+        g6_process()
+    if "g7" in which:
+        g7_tagger()
