@@ -1,0 +1,121 @@
+/* libcubehip — C ABI of the MI355X (gfx950) kernels behind the NLP-Cube parser/tagger
+ * inference path.  Plain C: pointers are DEVICE pointers unless a name ends in _host, sizes
+ * are ints, every call is asynchronous on the given hipStream_t (passed as void*), returns
+ * 0 on success or a negative code (text via cube_last_error()).  The library allocates
+ * nothing: the caller owns every buffer, including the workspaces.
+ *
+ * The reference has no FFI; each entry point replaces PyTorch/NumPy calls the reference
+ * makes on this path (file:line under the reference checkout):
+ *
+ *   cube_gemm_bf16          torch.conv1d + BatchNorm1d(eval) + tanh*sigmoid gating
+ *                           (cube/networks/modules.py:334-344,462-479; parser.py:161-176),
+ *                           nn.Linear (+tanh/relu) (modules.py:28-52; parser.py:181-203;
+ *                           modules.py:568-579), LSTM input projections (parser.py:71-72,201)
+ *   cube_gather_rows        nn.Embedding lookups + torch.cat (modules.py:451-457;
+ *                           parser.py:140-154), unpack() (utils.py:17-32)
+ *   cube_masked_mean        WordGram masked mean (modules.py:480-483)
+ *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197)
+ *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
+ *   cube_bilstm_recurrent   torch.lstm recurrence, 1 layer, both directions (parser.py:201)
+ *   cube_biaffine_arc       PairwiseBilinear bmm + torch.softmax (modules.py:518-533;
+ *                           parser.py:214-216,425)
+ *   cube_mst_decode         ChuLiuEdmondsDecoder.decode (cube/networks/utils.py:565-577,
+ *                           520-563, 445-518, 404-443)
+ *   cube_label_score        Parser._get_labels gather + nn.Bilinear (parser.py:218-233;
+ *                           modules.py:536-547)
+ */
+#ifndef CUBE_HIP_H
+#define CUBE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUBE_OK 0
+#define CUBE_ERR_ARG (-1)      /* bad argument / shape the kernels do not support   */
+#define CUBE_ERR_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned  */
+#define CUBE_ERR_LAUNCH (-3)   /* HIP reported a launch error                       */
+
+const char* cube_last_error(void);
+int cube_abi_version(void);
+
+/* ---- fused bf16 MFMA GEMM / implicit Conv1d(k=taps) ------------------------------------
+ * C[r, n] = bias[n] + sum_{tap, c} A[r + tap - taps/2, c] * W[n, tap*Kc + c]
+ * where a row r belongs to the sequence r / seq_len and taps outside it read zeros
+ * (Conv1d zero padding).  A: bf16 [M, lda]; W: bf16 [N, taps*Kc] (n-major); Kc % 32 == 0,
+ * N % 128 == 0, lda % 8 == 0.  fp32 accumulation. */
+enum {
+  CUBE_EPI_F32 = 0,        /* out0 f32 [M, ldo0]: cols col0..col0+n_valid = C (+= if accumulate)  */
+  CUBE_EPI_BF16 = 1,       /* out0 bf16 = C                                                      */
+  CUBE_EPI_BF16_TANH = 2,  /* out0 bf16 = tanh(C)                                                */
+  CUBE_EPI_BF16_RELU = 3,  /* out0 bf16 = relu(C)                                                */
+  CUBE_EPI_GATE = 4        /* gated conv layer, see below                                        */
+};
+/* CUBE_EPI_GATE: N = 2*half output channels packed so that column
+ *   n = nb*128 + wc*64 + part*32 + j  holds channel (part ? half : 0) + nb*64 + wc*32 + j;
+ * g = tanh(C_a) * sigmoid(C_b) per channel ch.  Then
+ *   res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g (and nothing else)
+ *   out0 (bf16, optional): [row, col0+ch] = g
+ *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference) */
+typedef struct cube_gemm_args {
+  const void* A; int lda; int M; int seq_len; int taps; int Kc;
+  const void* W; int N; const float* bias;
+  int epilogue; int n_valid; int accumulate;
+  void* out0; int ldo0; int col0;
+  const int32_t* rowmap;     /* optional: output row = rowmap[r]; negative = drop the row */
+  float* res; int ld_res; int res_mode;
+  void* out1; int ldo1; int col1;
+  void* out2; int ldo2; int col2;
+} cube_gemm_args;
+int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
+
+/* dst[dst_rows ? dst_rows[i] : i, col0 .. col0+width) = table[idx ? idx[i] : 0, 0..width)   (bf16) */
+int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* table, int ld_table,
+                     const int32_t* idx, const int32_t* dst_rows, int n, void* stream);
+
+/* out[n, c] = bf16( sum_{p < len[n]} x[n*W + p, c] / max(len[n], 1) ),  x f32 [N*W, ld_x], c < C */
+int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C,
+                     void* out, int ld_out, void* stream);
+
+/* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
+ * bf16(e) -> dst_a[(b*(L+1) + i + 1), col_a..+P) and dst_b[same row, col_b..+P)            */
+int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K,
+                    void* dst_a, int ld_a, int col_a, void* dst_b, int ld_b, int col_b, void* stream);
+
+/* out[r] = first index of the maximum of x[r, col0 .. col0+n)   (x f32 [M, ld])             */
+int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream);
+
+/* One bidirectional LSTM layer's recurrence over a padded batch.
+ * gx f32 [B*T, 2*G] (G = 64*U, U = ceil(H/16)): input projections + both biases, gate columns
+ *   packed as dir*G + u*64 + gate*16 + j for hidden unit u*16+j (gate order i,f,g,o).
+ * whh bf16 [2][G][KH] (KH = 32*ceil(H/32)): recurrent weights, row = packed gate column.
+ * out bf16 [B*T, ld_out]: h_fwd -> cols [col0, col0+H), h_bwd -> [col0+H, col0+2H).        */
+int cube_bilstm_recurrent(const float* gx, const void* whh, int B, int T, int H,
+                          void* out, int ld_out, int col0, void* stream);
+
+/* Arc scores + row softmax.  u bf16 [B*T, ld_u] (= [h1;1] W), h2 bf16 [B*T, ld_h2] (cols
+ * col_h2..col_h2+D), D % 32 == 0.  logits/probs f32 [B, T-1, T]: [b,i,j] = u[b,i+1,:].h2[b,j,:],
+ * probs = softmax over all T columns (pads included, as the reference does).                */
+int cube_biaffine_arc(const void* u, int ld_u, const void* h2, int ld_h2, int col_h2, int D,
+                      int B, int T, float* logits, float* probs, void* stream);
+
+/* Chu-Liu-Edmonds single-root decoding.  probs f32 [B, L, L+1], lens int32 [B] ->
+ * heads int32 [B, L] (0 at pads), status int32 [B] (0 ok, 1 = no tree: the reference asserts).
+ * workspace: cube_mst_workspace_bytes(B, L) bytes.                                          */
+size_t cube_mst_workspace_bytes(int B, int L);
+int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L,
+                    int32_t* heads, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Label scores for the decoded heads.  hl bf16 [B*T, ld_hl]: x1 = cols [0, D), x2 = cols
+ * [col_x2, col_x2+D) (each with its constant-1 column inside D), D % 32 == 0.
+ * wl bf16 [n_labels][D][D] ([o][q][p] = W[o,p,q]); bias f32 [n_labels];
+ * logits f32 [B, L, n_labels]: [b,i,o] = x1[b,i+1]^T W[o] x2[b, head] + bias[o], head =
+ * heads[b,i] if i < lens[b] else 0.  labels int32 [B, L] = argmax_o.                        */
+int cube_label_score(const void* hl, int ld_hl, int col_x2, int D, const void* wl, const float* bias,
+                     int n_labels, const int32_t* heads, const int32_t* lens, int B, int L,
+                     float* logits, int32_t* labels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libcubehip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CUBE_WAVE 64
+
+// error reporting (thread-local text returned by cube_last_error)
+void cube_set_error(const char* fmt, ...);
+#define CUBE_FAIL(code, ...)      \
+  do {                            \
+    cube_set_error(__VA_ARGS__);  \
+    return (code);                \
+  } while (0)
+#define CUBE_CHECK_LAUNCH(name)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) CUBE_FAIL(-3, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float x) {  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  bf16_t h = (bf16_t)x;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error < 2e-7
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}

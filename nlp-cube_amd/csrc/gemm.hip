@@ -1,0 +1,238 @@
+// Fused bf16 MFMA GEMM / implicit Conv1d for gfx950.
+//
+// One kernel serves every dense contraction on the parser path: the gated Conv1d(k=5) stacks
+// (5 shifted K-slices of the same activation rows, no im2col), the Linear layers and the LSTM
+// input projections.  128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x16_bf16; BK = 32; A and B tiles register-staged into a double-buffered,
+// padded (80-byte rows: conflict-free ds_read_b128) LDS image; one barrier per K-step.
+// Epilogues are fused: bias, tanh / relu, the tanh*sigmoid gate with residual accumulation,
+// row scatter (unpack).
+#include "common.h"
+#include "../../include/cube_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int ROWB = 80;                       // bytes per LDS row: 64 data + 16 pad
+constexpr int TILE_BYTES = (BM + BN) * ROWB;   // one stage: A rows then B rows
+
+struct GemmParams {
+  const uint16_t* A; int lda; int M; int seq_len; int taps; int Kc;
+  const uint16_t* W; int N; const float* bias;
+  int n_valid; int accumulate;
+  void* out0; int ldo0; int col0;
+  const int32_t* rowmap;
+  float* res; int ld_res; int res_mode;
+  uint16_t* out1; int ldo1; int col1;
+  uint16_t* out2; int ldo2; int col2;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int ksteps_per_tap = p.Kc / BK;
+  const int nk = p.taps * ksteps_per_tap;
+  const int ktot = p.taps * p.Kc;
+  const int half_taps = p.taps >> 1;
+
+  // staging: 512 16-byte chunks per operand tile, 2 per thread: chunk = tid + 256*i
+  int a_row[2], a_pos[2];
+  const uint16_t* b_src[2];
+  int kc8[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int chunk = tid + 256 * i;
+    const int row = chunk >> 2;
+    kc8[i] = (chunk & 3) * 8;
+    const int r = m0 + row;
+    a_row[i] = r;
+    a_pos[i] = (r < p.M) ? (r % p.seq_len) : -100000;
+    b_src[i] = p.W + (size_t)(n0 + row) * ktot + kc8[i];
+  }
+  const int st_off0 = (tid >> 2) * ROWB + (tid & 3) * 16;          // chunk tid
+  const int st_off1 = ((tid + 256) >> 2) * ROWB + (tid & 3) * 16;  // chunk tid+256
+
+  uint4 ra[2], rb[2];
+  auto load_step = [&](int s) {
+    const int tap = s / ksteps_per_tap;
+    const int kc0 = (s - tap * ksteps_per_tap) * BK;
+    const int d = tap - half_taps;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pp = a_pos[i] + d;
+      if (pp >= 0 && pp < p.seq_len) {
+        ra[i] = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row[i] + d) * p.lda + kc0 + kc8[i]);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+      }
+      rb[i] = *reinterpret_cast<const uint4*>(b_src[i] + (size_t)s * BK);
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* base = smem + buf * TILE_BYTES;
+    *reinterpret_cast<uint4*>(base + st_off0) = ra[0];
+    *reinterpret_cast<uint4*>(base + st_off1) = ra[1];
+    *reinterpret_cast<uint4*>(base + BM * ROWB + st_off0) = rb[0];
+    *reinterpret_cast<uint4*>(base + BM * ROWB + st_off1) = rb[1];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_rd = (wr * 64 + l31) * ROWB + lh * 16;
+  const int b_rd = BM * ROWB + (wc * 64 + l31) * ROWB + lh * 16;
+
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) load_step(s + 1);
+    const unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROWB + ks * 32);
+        fb[i] = *reinterpret_cast<const bf16x8*>(base + b_rd + i * 32 * ROWB + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nk) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of 32x32x16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if constexpr (EPI == CUBE_EPI_GATE) {
+    const int ch = blockIdx.x * 64 + wc * 32 + l31;
+    const float bias_a = p.bias[n0 + wc * 64 + l31];
+    const float bias_b = p.bias[n0 + wc * 64 + 32 + l31];
+    uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M && ch < p.n_valid) {
+          const float g = tanhf_(acc[i][0][r] + bias_a) * sigmoidf_(acc[i][1][r] + bias_b);
+          float* rp = p.res + (size_t)row * p.ld_res + ch;
+          float rs;
+          if (p.res_mode == 0) rs = g;
+          else if (p.res_mode == 1) rs = *rp + g;
+          else rs = *rp + 2.0f * g;
+          *rp = rs;
+          if (out0) out0[(size_t)row * p.ldo0 + p.col0 + ch] = f32_to_bf16(g);
+          if (p.out1) p.out1[(size_t)row * p.ldo1 + p.col1 + ch] = f32_to_bf16(rs + g);
+          if (p.out2) p.out2[(size_t)row * p.ldo2 + p.col2 + ch] = f32_to_bf16(rs + g);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= p.n_valid) continue;
+      const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= p.M) continue;
+          int orow = row;
+          if (p.rowmap) {
+            orow = p.rowmap[row];
+            if (orow < 0) continue;
+          }
+          float v = acc[i][j][r] + bias;
+          if constexpr (EPI == CUBE_EPI_F32) {
+            float* o = reinterpret_cast<float*>(p.out0) + (size_t)orow * p.ldo0 + p.col0 + col;
+            *o = p.accumulate ? (*o + v) : v;
+          } else {
+            if constexpr (EPI == CUBE_EPI_BF16_TANH) v = tanhf_(v);
+            if constexpr (EPI == CUBE_EPI_BF16_RELU) v = fmaxf(v, 0.f);
+            reinterpret_cast<uint16_t*>(p.out0)[(size_t)orow * p.ldo0 + p.col0 + col] = f32_to_bf16(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
+  if (!a) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null args");
+  if (a->M <= 0) return CUBE_OK;
+  if (!a->A || !a->W) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null operand");
+  if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: taps=%d", a->taps);
+  if (a->Kc <= 0 || a->Kc % BK) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BK);
+  if (a->N <= 0 || a->N % BN) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of %d", a->N, BN);
+  if (a->lda < a->Kc || a->lda % 8) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
+  if (!aligned16(a->A) || !aligned16(a->W)) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: operands must be 16-byte aligned");
+  const int seq = a->taps == 1 ? a->M : a->seq_len;
+  if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: M=%d not a multiple of seq_len=%d", a->M, seq);
+  GemmParams p;
+  p.A = (const uint16_t*)a->A; p.lda = a->lda; p.M = a->M; p.seq_len = seq; p.taps = a->taps; p.Kc = a->Kc;
+  p.W = (const uint16_t*)a->W; p.N = a->N; p.bias = a->bias;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : (a->epilogue == CUBE_EPI_GATE ? a->N / 2 : a->N);
+  p.accumulate = a->accumulate;
+  p.out0 = a->out0; p.ldo0 = a->ldo0; p.col0 = a->col0; p.rowmap = a->rowmap;
+  p.res = a->res; p.ld_res = a->ld_res; p.res_mode = a->res_mode;
+  p.out1 = (uint16_t*)a->out1; p.ldo1 = a->ldo1; p.col1 = a->col1;
+  p.out2 = (uint16_t*)a->out2; p.ldo2 = a->ldo2; p.col2 = a->col2;
+  if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: n_valid=%d > N=%d", p.n_valid, a->N);
+  dim3 grid(a->N / BN, (a->M + BM - 1) / BM), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case CUBE_EPI_F32:
+      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
+      hipLaunchKernelGGL(gemm_kernel<CUBE_EPI_F32>, grid, block, 0, st, p);
+      break;
+    case CUBE_EPI_BF16:
+    case CUBE_EPI_BF16_TANH:
+    case CUBE_EPI_BF16_RELU:
+      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
+      if (a->epilogue == CUBE_EPI_BF16) hipLaunchKernelGGL(gemm_kernel<CUBE_EPI_BF16>, grid, block, 0, st, p);
+      else if (a->epilogue == CUBE_EPI_BF16_TANH) hipLaunchKernelGGL(gemm_kernel<CUBE_EPI_BF16_TANH>, grid, block, 0, st, p);
+      else hipLaunchKernelGGL(gemm_kernel<CUBE_EPI_BF16_RELU>, grid, block, 0, st, p);
+      break;
+    case CUBE_EPI_GATE: {
+      const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile
+      if (half > a->N / 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate n_valid=%d > N/2", half);
+      if (!a->res || a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs res[M, >=%d]", half);
+      if (a->res_mode < 0 || a->res_mode > 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: res_mode=%d", a->res_mode);
+      if (a->rowmap) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: rowmap is not supported by the gate epilogue");
+      if (a->out0 && a->ldo0 < a->col0 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
+      if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out1/ldo1");
+      if (a->out2 && a->ldo2 < a->col2 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out2/ldo2");
+      if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
+      hipLaunchKernelGGL(gemm_kernel<CUBE_EPI_GATE>, grid, block, 0, st, p);
+      break;
+    }
+    default:
+      CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: unknown epilogue %d", a->epilogue);
+  }
+  CUBE_CHECK_LAUNCH("cube_gemm_bf16");
+  return CUBE_OK;
+}

@@ -1,0 +1,128 @@
+// Persistent recurrent-step kernel of one bidirectional LSTM layer (gfx950).
+//
+// One workgroup owns (direction, 16 sentences) for the whole sequence: it walks the T steps
+// itself, so the serial dependency never leaves the CU.  Wave w owns the hidden units
+// [16w, 16w+16): its four 16x16 accumulator tiles are the i,f,g,o pre-activations of the SAME
+// (sentence, hidden unit) in the SAME lane/register, so the gate nonlinearities and the cell
+// update are register-local (no shuffles, no LDS); only h_t crosses waves, through a
+// double-buffered bf16 LDS image that is the A operand of the next step's MFMAs
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  The input projections (all timesteps at once)
+// come from cube_gemm_bf16 and are prefetched one step ahead.
+#include "common.h"
+#include "../../include/cube_hip.h"
+
+namespace {
+
+constexpr int ROWS = 16;  // sentences per workgroup (= MFMA M)
+
+template <int KSTEPS>
+__global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __restrict__ whh, int B, int T, int H,
+                              uint16_t* __restrict__ out, int ld_out, int col0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KH = KSTEPS * 32;
+  constexpr int HROW = KH * 2 + 16;  // bytes per h row (padded: conflict-free ds_read_b128)
+  const int U = (H + 15) >> 4;
+  const int G = U * 64;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * ROWS;
+  const int lane = threadIdx.x & 63;
+  const int u = threadIdx.x >> 6;  // hidden-unit group of this wave
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // zero both h images (h_{-1} = 0, K padding = 0)
+  for (int i = threadIdx.x * 4; i < 2 * ROWS * HROW; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(smem + i) = 0u;
+  __syncthreads();
+
+  const uint16_t* wbase = whh + ((size_t)dir * G + (size_t)u * 64 + l15) * KH + lq * 8;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hid = u * 16 + l15;
+  const size_t gx_ld = (size_t)2 * G;
+  const float* gx_col = gx + (size_t)dir * G + u * 64 + l15;
+
+  f32x4 nxt[4];
+  auto load_gx = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + lq * 4 + r;
+      if (b < B) {
+        const float* p = gx_col + ((size_t)b * T + t) * gx_ld;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nxt[g][r] = p[g * 16];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nxt[g][r] = 0.f;
+      }
+    }
+  };
+
+  load_gx(dir ? T - 1 : 0);
+  int cur = 0;
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = nxt[g];
+    if (s + 1 < T) load_gx(dir ? t - 1 : t + 1);
+
+    const unsigned char* hb = smem + cur * ROWS * HROW + l15 * HROW + lq * 16;
+    // W_hh is re-streamed from L2 every step: 7 k-steps x 4 gates of B fragments are 112 VGPRs per
+    // wave, more than the 128-register budget of a 13-wave workgroup leaves.  Laundering the
+    // pointer keeps hipcc from hoisting (and then spilling) the loads out of the time loop.
+    const uint16_t* wb = wbase;
+    asm volatile("" : "+v"(wb));
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(hb + ks * 64);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + (size_t)g * 16 * KH + ks * 32);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc[g], 0, 0, 0);
+      }
+    }
+    unsigned char* hn = smem + (cur ^ 1) * ROWS * HROW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = sigmoidf_(acc[0][r]);
+      const float fg = sigmoidf_(acc[1][r]);
+      const float gg = tanhf_(acc[2][r]);
+      const float og = sigmoidf_(acc[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      const uint16_t hv = f32_to_bf16(og * tanhf_(c[r]));
+      const int row = lq * 4 + r;
+      *reinterpret_cast<uint16_t*>(hn + row * HROW + hid * 2) = hv;
+      const int b = b0 + row;
+      if (b < B && hid < H) out[((size_t)b * T + t) * ld_out + col0 + dir * H + hid] = hv;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int cube_bilstm_recurrent(const float* gx, const void* whh, int B, int T, int H, void* out, int ld_out,
+                                     int col0, void* stream) {
+  if (B <= 0 || T <= 0) return CUBE_OK;
+  if (!gx || !whh || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: null pointer");
+  if (H <= 0 || H > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: rnn_size=%d unsupported (1..256)", H);
+  if (col0 < 0 || col0 + 2 * H > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: bad output columns");
+  if ((uintptr_t)whh % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_bilstm_recurrent: whh must be 16-byte aligned");
+  const int U = (H + 15) / 16;
+  const int ksteps = (H + 31) / 32;
+  const int KH = ksteps * 32;
+  const size_t lds = (size_t)2 * ROWS * (KH * 2 + 16);
+  dim3 grid((B + ROWS - 1) / ROWS, 2), block(64 * U);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(KS)                                                                                                  \
+  case KS:                                                                                                          \
+    hipLaunchKernelGGL(bilstm_kernel<KS>, grid, block, lds, st, gx, (const uint16_t*)whh, B, T, H, (uint16_t*)out, \
+                       ld_out, col0);                                                                               \
+    break;
+  switch (ksteps) {
+    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    default: CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: ksteps=%d", ksteps);
+  }
+#undef LAUNCH
+  CUBE_CHECK_LAUNCH("cube_bilstm_recurrent");
+  return CUBE_OK;
+}

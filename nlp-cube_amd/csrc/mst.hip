@@ -1,0 +1,491 @@
+// Chu-Liu-Edmonds single-root head decoding, one wavefront per task, score matrix in LDS.
+//
+// Restates the reference decoder (cube/networks/utils.py:400-577) with the same fp64
+// arithmetic and the same tie-breaks (first maximal index in the current node order; the
+// cycle whose smallest node comes last), so heads are identical wherever the reference's own
+// comparisons are not decided by the last bits of a log-sum.
+//
+//   mst_first_kernel   one wave per sentence: builds S (fp64, n x n, odd leading dimension ->
+//                      conflict-free row-per-lane scans) from the padded-softmax probabilities,
+//                      runs the contraction loop, and either emits the heads (exactly one root)
+//                      or appends one task per candidate root to a device-side task list.
+//   mst_root_kernel    one wave per (sentence, candidate root): the reference's `set_root` +
+//                      CLE + log-probability score.  Grid-strides over the device-side task
+//                      count: no host round trip.
+//   mst_select_kernel  first strictly-best candidate per sentence (utils.py:548-555), or
+//                      status 1 when every candidate scores -inf (the reference asserts).
+//
+// Contraction keeps node ids (= LDS rows/columns) in place: a logical order list gives the
+// reference's index order (non-cycle nodes in order, contracted node last), the contracted node
+// reuses the slot of the cycle's first node, and every level appends a byte record
+// [m, c, cycle nodes, their heads, best-cycle-member per outside head, best-cycle-member per
+// outside dependent] that the expansion pass replays backwards.  Cycles are found with 8 rounds
+// of pointer doubling instead of a recursive Tarjan.
+#include "common.h"
+#include "../../include/cube_hip.h"
+
+namespace {
+
+constexpr int MST_MAX_N = 130;  // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
+
+struct MstLds {
+  double* S; int ld;
+  double* hval; double* dval; double* cs;
+  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn;
+  uint8_t* rec; int rec_cap;
+};
+
+__host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
+__host__ __device__ inline size_t mst_lds_bytes(int n) {
+  const int ld = n | 1;
+  const int np = mst_np(n);
+  return (size_t)n * ld * 8 + (size_t)3 * np * 8 + (size_t)12 * np + (size_t)(n * n + 3 * n + 16);
+}
+
+__device__ inline MstLds mst_carve(unsigned char* smem, int n) {
+  MstLds m;
+  const int np = mst_np(n);
+  m.ld = n | 1;
+  m.S = reinterpret_cast<double*>(smem);
+  unsigned char* q = smem + (size_t)n * m.ld * 8;
+  m.hval = reinterpret_cast<double*>(q); q += np * 8;
+  m.dval = reinterpret_cast<double*>(q); q += np * 8;
+  m.cs = reinterpret_cast<double*>(q); q += np * 8;
+  uint8_t** arr[12] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn};
+  for (int i = 0; i < 12; ++i) { *arr[i] = q; q += np; }
+  m.rec = q;
+  m.rec_cap = n * n + 3 * n + 16;
+  return m;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Runs the contraction/expansion on the n x n matrix in `m.S` (row = dependent, column = head;
+// row 0 is virtual: e_0).  Diagonal entries must be zero on entry.  Result: m.tree[k] = head.
+// Returns false if the record area overflowed (cannot happen for n <= MST_MAX_N).
+__device__ bool cle_run(const MstLds& m, int n, int lane) {
+  double* S = m.S;
+  const int ld = m.ld;
+  for (int k = lane; k < n; k += 64) { m.order[k] = (uint8_t)k; m.pos[k] = (uint8_t)k; m.alive[k] = 1; }
+  __syncthreads();
+  int cur = n;       // nodes at this level
+  int rec_end = 0;   // bytes of records written
+  int levels = 0;
+  while (true) {
+    // ---- 1. best head per node, first maximum in logical order
+    for (int li = lane; li < cur; li += 64) {
+      const int k = m.order[li];
+      if (k == 0) { m.tree[0] = 0; continue; }
+      const double* row = S + (size_t)k * ld;
+      double best = row[0];
+      int bi = 0;
+      for (int lj = 1; lj < cur; ++lj) {
+        const int j = m.order[lj];
+        const double v = row[j];
+        if (v > best || (v != v && best == best)) { best = v; bi = j; }
+      }
+      m.tree[k] = (uint8_t)bi;
+    }
+    __syncthreads();
+    // ---- 2. cycles by pointer doubling: p = f^(2^r), mn = smallest logical position on the walk
+    for (int li = lane; li < cur; li += 64) {
+      const int k = m.order[li];
+      m.p0[k] = m.tree[k];
+      m.mn0[k] = (uint8_t)li;
+      m.flag[k] = 0;
+    }
+    __syncthreads();
+    uint8_t *pa = m.p0, *pb = m.p1, *ma = m.mn0, *mb = m.mn1;
+    for (int span = 1; span < cur; span <<= 1) {
+      for (int li = lane; li < cur; li += 64) {
+        const int k = m.order[li];
+        const int q = pa[k];
+        pb[k] = pa[q];
+        mb[k] = min(ma[k], ma[q]);
+      }
+      __syncthreads();
+      uint8_t* t = pa; pa = pb; pb = t;
+      t = ma; ma = mb; mb = t;
+    }
+    for (int li = lane; li < cur; li += 64) m.flag[pa[m.order[li]]] = 1;  // eventual image = nodes on loops
+    __syncthreads();
+    int chosen = -1;
+    for (int li = lane; li < cur; li += 64) {
+      const int k = m.order[li];
+      if (k != 0 && m.flag[k]) chosen = max(chosen, (int)ma[k]);
+    }
+    chosen = wave_max_i(chosen);
+    if (chosen < 0) break;  // a tree
+    // ---- 3. ordered lists: cycle nodes C (logical order), survivors N (logical order)
+    int c = 0, nn = 0;
+    for (int base = 0; base < cur; base += 64) {
+      const int li = base + lane;
+      int k = 0;
+      bool in_c = false, in_n = false;
+      if (li < cur) {
+        k = m.order[li];
+        in_c = (k != 0) && m.flag[k] && (ma[k] == chosen);
+        in_n = !in_c;
+      }
+      const unsigned long long bc = __ballot(in_c), bn = __ballot(in_n);
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      if (in_c) { m.clist[c + __popcll(bc & below)] = (uint8_t)k; m.incyc[k] = 1; }
+      if (in_n) { m.p1[nn + __popcll(bn & below)] = (uint8_t)k; m.incyc[k] = 0; }  // p1 reused: new order list
+      c += __popcll(bc);
+      nn += __popcll(bn);
+    }
+    uint8_t* norder = m.p1;
+    __syncthreads();
+    const int slot_m = m.clist[0];
+    // rank of each survivor among surviving slots in ascending slot id (record addressing)
+    {
+      int run = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const bool ok = (s < n) && m.alive[s] && !m.incyc[s];
+        const unsigned long long bm = __ballot(ok);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (ok) m.rankn[s] = (uint8_t)(run + __popcll(bm & below));
+        run += __popcll(bm);
+      }
+    }
+    // record header + cycle
+    const int need = 2 + 2 * c + 2 * nn;
+    if (rec_end + need > m.rec_cap) return false;
+    uint8_t* rec = m.rec + rec_end;
+    if (lane == 0) { rec[0] = (uint8_t)cur; rec[1] = (uint8_t)c; }
+    for (int i = lane; i < c; i += 64) {
+      const int k = m.clist[i];
+      rec[2 + i] = (uint8_t)k;
+      rec[2 + c + i] = m.tree[k];
+      m.cs[i] = S[(size_t)k * ld + m.tree[k]];
+    }
+    __syncthreads();
+    // ---- 4. product of the cycle's arc scores, in cycle order
+    double total = 1.0;
+    for (int i = 0; i < c; ++i) total = total * m.cs[i];
+    // ---- 5. best entry/exit of the contracted node per surviving node
+    uint8_t* rec_h = rec + 2 + 2 * c;
+    uint8_t* rec_d = rec_h + nn;
+    for (int a = lane; a < nn; a += 64) {
+      const int j = norder[a];
+      double hb = S[(size_t)m.clist[0] * ld + j] / m.cs[0] * total;
+      int hi = 0;
+      double db = (j == 0) ? 0.0 : S[(size_t)j * ld + m.clist[0]];
+      int di = 0;
+      for (int i = 1; i < c; ++i) {
+        const int k = m.clist[i];
+        const double hv = S[(size_t)k * ld + j] / m.cs[i] * total;
+        if (hv > hb || (hv != hv && hb == hb)) { hb = hv; hi = i; }
+        const double dv = (j == 0) ? 0.0 : S[(size_t)j * ld + k];
+        if (dv > db || (dv != dv && db == db)) { db = dv; di = i; }
+      }
+      m.hval[a] = hb;
+      m.dval[a] = db;
+      rec_h[m.rankn[j]] = (uint8_t)hi;
+      rec_d[m.rankn[j]] = (uint8_t)di;
+    }
+    __syncthreads();
+    // ---- 6. contracted node takes the slot of the cycle's first node and goes last in the order
+    for (int a = lane; a < nn; a += 64) {
+      const int j = norder[a];
+      S[(size_t)slot_m * ld + j] = m.hval[a];
+      if (j != 0) S[(size_t)j * ld + slot_m] = m.dval[a];
+      m.order[a] = (uint8_t)j;
+      m.pos[j] = (uint8_t)a;
+    }
+    for (int i = 1 + lane; i < c; i += 64) m.alive[m.clist[i]] = 0;
+    if (lane == 0) {
+      S[(size_t)slot_m * ld + slot_m] = 0.0;
+      m.order[nn] = (uint8_t)slot_m;
+      m.pos[slot_m] = (uint8_t)nn;
+    }
+    __syncthreads();
+    cur = nn + 1;
+    rec_end += need;
+    ++levels;
+  }
+  // ---- expansion, deepest level first (utils.py:491-518)
+  __syncthreads();
+  int off_stack_end = rec_end;
+  // records are variable length: walk forward once to find offsets is O(levels^2) if repeated,
+  // so walk backwards using the stored sizes: each record's length is 2 + 2*m - ... recomputed
+  // from its header; keep a small offset table in the (now free) hval area.
+  int* offs = reinterpret_cast<int*>(m.hval);  // n entries of 4 bytes fit in np*8 bytes
+  {
+    int o = 0, l = 0;
+    while (o < rec_end) {  // uniform loop, every lane walks the headers
+      if (lane == 0) offs[l] = o;
+      const int mm = m.rec[o], cc = m.rec[o + 1];
+      o += 2 + 2 * cc + 2 * (mm - cc);
+      ++l;
+    }
+  }
+  __syncthreads();
+  (void)off_stack_end;
+  for (int l = levels - 1; l >= 0; --l) {
+    const uint8_t* rec = m.rec + offs[l];
+    const int mm = rec[0], c = rec[1];
+    const int nn = mm - c;
+    const uint8_t* cl = rec + 2;
+    const uint8_t* tc = rec + 2 + c;
+    const uint8_t* rec_h = rec + 2 + 2 * c;
+    const uint8_t* rec_d = rec_h + nn;
+    const int slot_m = cl[0];
+    const int head_m = m.tree[slot_m];
+    __syncthreads();
+    int run = 0, rank_head = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int s = base + lane;
+      const bool ok = (s < n) && m.alive[s] && (s != slot_m);
+      const unsigned long long bm = __ballot(ok);
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int rk = run + __popcll(bm & below);
+      if (ok && m.tree[s] == slot_m) m.tree[s] = cl[rec_d[rk]];
+      if (head_m >= base && head_m < base + 64) rank_head = run + __popcll(bm & ((head_m - base) == 0 ? 0ull : (~0ull >> (64 - (head_m - base)))));
+      run += __popcll(bm);
+    }
+    __syncthreads();
+    for (int i = lane; i < c; i += 64) { m.tree[cl[i]] = tc[i]; m.alive[cl[i]] = 1; }
+    __syncthreads();
+    if (lane == 0) m.tree[cl[rec_h[rank_head]]] = (uint8_t)head_m;
+    __syncthreads();
+  }
+  return true;
+}
+
+// S[k][j] for k >= 1 from the probability tensor (utils.py:569-574): crop to n columns, zero diagonal
+__device__ inline void build_scores(const MstLds& m, const float* p, int n, int T, int lane, int root) {
+  for (int k = 1; k < n; ++k) {
+    const float* pr = p + (size_t)(k - 1) * T;
+    double* row = m.S + (size_t)k * m.ld;
+    for (int j = lane; j < n; j += 64) {
+      double v = (j == k) ? 0.0 : (double)pr[j];
+      if (root > 0) {  // set_root (utils.py:537-543)
+        if (j == 0) v = (k == root) ? 1.0 : 0.0;
+        else if (k == root) v = 0.0;
+      }
+      row[j] = v;
+    }
+  }
+  __syncthreads();
+}
+
+struct MstWs {
+  int32_t* ntasks;      // [4] (16-byte block at the start of the workspace)
+  int32_t* sent_base;   // [B]
+  int32_t* sent_cnt;    // [B]
+  int32_t* task_sent;   // [B*L]
+  int32_t* task_root;   // [B*L]
+  double* task_score;   // [B*L]
+  uint8_t* task_tree;   // [B*L][L+1]
+};
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ inline size_t mst_ws_bytes(int B, int L) {
+  const size_t nt = (size_t)B * L;
+  return 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1));
+}
+__host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
+  MstWs w;
+  unsigned char* q = (unsigned char*)ws;
+  const size_t nt = (size_t)B * L;
+  w.ntasks = (int32_t*)q; q += 16;
+  w.sent_base = (int32_t*)q; q += align16(4 * (size_t)B);
+  w.sent_cnt = (int32_t*)q; q += align16(4 * (size_t)B);
+  w.task_sent = (int32_t*)q; q += align16(4 * nt);
+  w.task_root = (int32_t*)q; q += align16(4 * nt);
+  w.task_score = (double*)q; q += align16(8 * nt);
+  w.task_tree = (uint8_t*)q;
+  return w;
+}
+
+__global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
+                                                       int B, int L, int32_t* heads, int32_t* status, MstWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int T = L + 1;
+  int len = lens[b];
+  len = min(max(len, 0), L);
+  const int n = len + 1;
+  int32_t* hb = heads + (size_t)b * L;
+  for (int i = lane; i < L; i += 64) hb[i] = 0;
+  if (lane == 0) { ws.sent_cnt[b] = 0; ws.sent_base[b] = 0; status[b] = 0; }
+  if (len == 0) return;
+  const float* p = probs + (size_t)b * L * T;
+  MstLds m = mst_carve(smem, n);
+  build_scores(m, p, n, T, lane, 0);
+  if (!cle_run(m, n, lane)) { if (lane == 0) status[b] = 2; return; }
+  __syncthreads();
+  // roots (utils.py:525-534)
+  int nroots = 0;
+  for (int base = 1; base < n; base += 64) {
+    const int k = base + lane;
+    nroots += __popcll(__ballot(k < n && m.tree[k] == 0));
+  }
+  if (nroots == 1) {
+    for (int k = 1 + lane; k < n; k += 64) hb[k - 1] = m.tree[k];
+    return;
+  }
+  // candidate flags in m.flag[k]
+  int ncand = 0;
+  if (nroots >= 2) {
+    for (int k = lane; k < n; k += 64) m.flag[k] = (k >= 1 && m.tree[k] == 0) ? 1 : 0;
+    ncand = nroots;
+  } else {
+    const double thr = 1.0 / (double)n;
+    for (int base = 0; base < n; base += 64) {
+      const int k = base + lane;
+      const bool ok = (k >= 1 && k < n) && ((double)p[(size_t)(k - 1) * T] >= thr);
+      if (k < n) m.flag[k] = ok ? 1 : 0;
+      ncand += __popcll(__ballot(ok));
+    }
+    if (ncand == 0) {  // 1 + argmax(scores[1:, 0]), first maximum
+      __syncthreads();
+      if (lane == 0) {
+        float best = p[0];
+        int bi = 1;
+        for (int k = 2; k < n; ++k) {
+          const float v = p[(size_t)(k - 1) * T];
+          if (v > best || (v != v && best == best)) { best = v; bi = k; }
+        }
+        m.flag[bi] = 1;
+      }
+      ncand = 1;
+    }
+  }
+  __syncthreads();
+  int base_task = 0;
+  if (lane == 0) {
+    base_task = atomicAdd(ws.ntasks, ncand);
+    ws.sent_base[b] = base_task;
+    ws.sent_cnt[b] = ncand;
+    status[b] = -1;
+  }
+  base_task = __shfl(base_task, 0);
+  int run = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int k = base + lane;
+    const bool ok = (k < n) && m.flag[k];
+    const unsigned long long bm = __ballot(ok);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (ok) {
+      const int t = base_task + run + __popcll(bm & below);
+      ws.task_sent[t] = b;
+      ws.task_root[t] = k;
+    }
+    run += __popcll(bm);
+  }
+}
+
+__global__ __launch_bounds__(64) void mst_root_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
+                                                      int B, int L, MstWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int T = L + 1;
+  const int ntasks = min(*ws.ntasks, B * L);
+  for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+    __syncthreads();
+    const int b = ws.task_sent[t];
+    const int root = ws.task_root[t];
+    const int n = min(max(lens[b], 0), L) + 1;
+    const float* p = probs + (size_t)b * L * T;
+    MstLds m = mst_carve(smem, n);
+    build_scores(m, p, n, T, lane, root);
+    uint8_t* tt = ws.task_tree + (size_t)t * T;
+    if (!cle_run(m, n, lane)) {
+      if (lane == 0) ws.task_score[t] = -INFINITY;
+      continue;
+    }
+    __syncthreads();
+    // tree score (utils.py:551-552): sum of log of the selected entries of the set_root matrix
+    double s = 0.0;
+    bool all_nz = true;
+    for (int k = 1 + lane; k < n; k += 64) {
+      const int h = m.tree[k];
+      tt[k] = (uint8_t)h;
+      double v;
+      if (k == root) v = (h == 0) ? 1.0 : 0.0;
+      else if (h == 0 || h == k) v = 0.0;
+      else v = (double)p[(size_t)(k - 1) * T + h];
+      if (v == 0.0) all_nz = false; else s += log(v);
+    }
+    all_nz = (__ballot(!all_nz) == 0ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const double root_score = (double)p[(size_t)(root - 1) * T];
+    double sc = -INFINITY;
+    if (all_nz) sc = s + log(root_score);
+    if (lane == 0) ws.task_score[t] = sc;
+  }
+}
+
+__global__ __launch_bounds__(64) void mst_select_kernel(const int32_t* __restrict__ lens, int B, int L, int32_t* heads,
+                                                        int32_t* status, MstWs ws) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int cnt = ws.sent_cnt[b];
+  if (cnt <= 0) return;
+  const int base = ws.sent_base[b];
+  double best = -INFINITY;
+  int bt = -1;
+  for (int i = 0; i < cnt; ++i) {
+    const double sc = ws.task_score[base + i];
+    if (sc > best) { best = sc; bt = base + i; }
+  }
+  if (bt < 0) {
+    if (lane == 0) status[b] = 1;
+    return;
+  }
+  const int n = min(max(lens[b], 0), L) + 1;
+  const uint8_t* tt = ws.task_tree + (size_t)bt * (L + 1);
+  for (int k = 1 + lane; k < n; k += 64) heads[(size_t)b * L + k - 1] = tt[k];
+  if (lane == 0) status[b] = 0;
+}
+
+}  // namespace
+
+extern "C" size_t cube_mst_workspace_bytes(int B, int L) {
+  if (B <= 0 || L <= 0) return 16;
+  return mst_ws_bytes(B, L);
+}
+
+extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || L <= 0) return CUBE_OK;
+  if (!probs || !lens || !heads || !status || !workspace) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: null pointer");
+  if (L + 1 > MST_MAX_N) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N - 1);
+  if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
+  if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = mst_lds_bytes(L + 1);
+  static size_t lds_set_first = 0, lds_set_root = 0;
+  if (lds > 65536) {
+    if (lds > lds_set_first) {
+      if (hipFuncSetAttribute((const void*)mst_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
+      lds_set_first = lds;
+    }
+    if (lds > lds_set_root) {
+      if (hipFuncSetAttribute((const void*)mst_root_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
+      lds_set_root = lds;
+    }
+  }
+  MstWs ws = mst_ws_carve(workspace, B, L);
+  if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
+  hipLaunchKernelGGL(mst_first_kernel, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
+  CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
+  int nblk = B * L;
+  if (nblk > 4096) nblk = 4096;
+  hipLaunchKernelGGL(mst_root_kernel, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+  CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
+  hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
+  CUBE_CHECK_LAUNCH("cube_mst_decode(select)");
+  return CUBE_OK;
+}

@@ -1,0 +1,143 @@
+// Row-wise HBM-bound helpers of the parser path: embedding gathers into concat buffers,
+// the WordGram masked mean, the external-embedding finish and arg-max over logits.
+// All are coalesced along the row (16-byte vector accesses where the layout allows).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+#include "../../include/cube_hip.h"
+
+static thread_local char g_err[512] = "";
+void cube_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* cube_last_error(void) { return g_err; }
+extern "C" int cube_abi_version(void) { return 1; }
+
+namespace {
+
+// ---- gather: one wave per row-chunk, 2-byte granularity fallback when not 16-byte alignable
+__global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, int ld_dst, int col0, int width,
+                                                          const uint16_t* table, int ld_table,
+                                                          const int32_t* idx, const int32_t* dst_rows, int n,
+                                                          int vec_ok) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n; i += nwaves) {
+    const int src_row = idx ? idx[i] : 0;
+    const int dst_row = dst_rows ? dst_rows[i] : i;
+    if (dst_row < 0) continue;
+    const uint16_t* s = table + (size_t)src_row * ld_table;
+    uint16_t* d = dst + (size_t)dst_row * ld_dst + col0;
+    if (vec_ok) {
+      for (int c = lane * 8; c < width; c += 64 * 8)
+        *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(s + c);
+    } else {
+      for (int c = lane; c < width; c += 64) d[c] = s[c];
+    }
+  }
+}
+
+// ---- masked mean over the W character positions of each word
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* x, int ld_x, const int32_t* len, int N, int W,
+                                                          int C, uint16_t* out, int ld_out) {
+  const int n = blockIdx.x;
+  if (n >= N) return;
+  const int l = min(max(len[n], 0), W);
+  const float den = (float)max(len[n], 1);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    const float* p = x + (size_t)n * W * ld_x + c;
+    for (int q = 0; q < l; ++q) s += p[(size_t)q * ld_x];
+    out[(size_t)n * ld_out + c] = f32_to_bf16(s / den);
+  }
+}
+
+__global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int P, float K,
+                                                         uint16_t* da, int ld_a, int col_a, uint16_t* db, int ld_b,
+                                                         int col_b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * L * P) return;
+  const int r = t / P, c = t - r * P;
+  const int b = r / L, i = r - b * L;
+  const uint16_t v = f32_to_bf16(tanhf_(acc[(size_t)r * ld_acc + c] / K));
+  const size_t orow = (size_t)b * (L + 1) + i + 1;
+  if (da) da[orow * ld_a + col_a + c] = v;
+  if (db) db[orow * ld_b + col_b + c] = v;
+}
+
+// ---- arg-max (first maximal index, like torch.argmax / numpy.argmax): one wave per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld, int col0, int n, int M, int32_t* out) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* p = x + (size_t)row * ld + col0;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < n; c += 64) {
+    const float v = p[c];
+    if (v > best || (v != v && best == best)) { best = v; bi = c; }  // NaN counts as maximal
+  }
+  if (bi == 0x7fffffff && lane < n) bi = lane;  // all -inf in this lane's slice
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    const bool take = (ob > best) || (ob == best && oi < bi) || (ob != ob && best == best) ||
+                      (ob != ob && best != best && oi < bi);
+    if (take) { best = ob; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+}  // namespace
+
+extern "C" int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* table, int ld_table,
+                                const int32_t* idx, const int32_t* dst_rows, int n, void* stream) {
+  if (n <= 0 || width <= 0) return CUBE_OK;
+  if (!dst || !table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: null pointer");
+  if (col0 < 0 || col0 + width > ld_dst || width > ld_table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: bad columns");
+  const int vec_ok = (width % 8 == 0) && (col0 % 8 == 0) && (ld_dst % 8 == 0) && (ld_table % 8 == 0) &&
+                     ((uintptr_t)dst % 16 == 0) && ((uintptr_t)table % 16 == 0);
+  const int waves_per_block = 4;
+  int blocks = (n + waves_per_block - 1) / waves_per_block;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, ld_dst, col0,
+                     width, (const uint16_t*)table, ld_table, idx, dst_rows, n, vec_ok);
+  CUBE_CHECK_LAUNCH("cube_gather_rows");
+  return CUBE_OK;
+}
+
+extern "C" int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C, void* out,
+                                int ld_out, void* stream) {
+  if (N <= 0) return CUBE_OK;
+  if (!x || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ld_x, len, N, W, C,
+                     (uint16_t*)out, ld_out);
+  CUBE_CHECK_LAUNCH("cube_masked_mean");
+  return CUBE_OK;
+}
+
+extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K, void* dst_a, int ld_a,
+                               int col_a, void* dst_b, int ld_b, int col_b, void* stream) {
+  if (B <= 0 || L <= 0 || P <= 0) return CUBE_OK;
+  if (!acc || K <= 0 || P > ld_acc) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
+  if ((dst_a && col_a + P > ld_a) || (dst_b && col_b + P > ld_b)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad columns");
+  const int total = B * L * P;
+  hipLaunchKernelGGL(ext_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, ld_acc, B, L,
+                     P, (float)K, (uint16_t*)dst_a, ld_a, col_a, (uint16_t*)dst_b, ld_b, col_b);
+  CUBE_CHECK_LAUNCH("cube_ext_finish");
+  return CUBE_OK;
+}
+
+extern "C" int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream) {
+  if (M <= 0) return CUBE_OK;
+  if (!x || !out || n <= 0 || col0 < 0 || col0 + n > ld) CUBE_FAIL(CUBE_ERR_ARG, "cube_argmax_rows: bad args");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, col0, n, M, out);
+  CUBE_CHECK_LAUNCH("cube_argmax_rows");
+  return CUBE_OK;
+}

@@ -1,0 +1,96 @@
+"""`Cube` / `CubeObj` — the user-facing boundary of the accelerated path.
+
+Mirror of the reference API (cube/api.py:39-128, 183-211): `Cube().load(lang, device)`,
+`cube(text_or_Document, flavour=None) -> Document`.  Only what `Cube.__call__` dispatches AFTER
+tokenization is implemented here: `lm_helper.apply(doc)` followed by
+`Parser.process(doc, collate, num_workers=0)`.  Raw-string input needs the tokenizer stage and
+the lemmatizer is a later stage — both out of scope — so a `str` raises NotImplementedError and
+lemmas are left untouched.  Model download (api.py:150-180) needs the network and is not done:
+the model directory `~/.nlpcube/3.0/<lang>` must already exist.
+"""
+import os
+from pathlib import Path
+from typing import Optional, Union
+
+import yaml
+
+from cube_amd.io_utils.config import ParserConfig
+from cube_amd.io_utils.encodings import Encodings
+from cube_amd.io_utils.objects import Document
+from cube_amd.networks.lm import LMHelperDummy, LMHelperPrecomputed
+from cube_amd.networks.parser import Parser
+from cube_amd.networks.utils import MorphoCollate
+
+
+class CubeObj:
+    """reference: cube/api.py:39-128 (parser-tagger part :91-106, dispatch :108-128)."""
+
+    def __init__(self, model_base: str, device: str = "cpu", lang: str = None, lm_helper=None):
+        path = "{0}-trf-tokenizer".format(model_base)
+        with open("{0}.yaml".format(path)) as f:
+            g_conf = yaml.safe_load(f)
+        self._lang2id = {}
+        for lng in g_conf["language_codes"]:
+            self._lang2id[lng] = len(self._lang2id)
+        self._default_lang_id = self._lang2id[g_conf["language_map"][lang]]
+        self._default_lang = lang
+        path = "{0}-trf-parser".format(model_base)
+        config = ParserConfig(filename="{0}.config".format(path))
+        if lm_helper is not None:
+            self._lm_helper = lm_helper
+        elif str(config.lm_model).startswith("dummy"):
+            self._lm_helper = LMHelperDummy()
+        else:
+            raise NotImplementedError(
+                "lm_model '%s' needs an external embedding model (out of scope, SURVEY.md §8f); pass "
+                "lm_helper=LMHelperPrecomputed(sizes) and set word.emb yourself" % config.lm_model)
+        encodings = Encodings()
+        encodings.load("{0}.encodings".format(path))
+        self._parser = Parser(config, encodings, language_codes=g_conf["language_codes"],
+                              ext_word_emb=self._lm_helper.get_embedding_size())
+        self._parser.load("{0}.best".format(path))
+        self._parser.to(device)
+        self._parser_collate = MorphoCollate(encodings)
+
+    def __call__(self, text: Union[str, Document], flavour: Optional[str] = None):
+        lang_id = self._default_lang_id
+        if flavour is not None:
+            if flavour not in self._lang2id:
+                print("Unsupported language flavour")
+                print("Please choose from: {0}".format(" ".join([k for k in self._lang2id])))
+                raise Exception("Unsupported language flavour\nPlease choose from: {0}".
+                                format(" ".join([k for k in self._lang2id])))
+            lang_id = self._lang2id[flavour]
+        if isinstance(text, str):
+            raise NotImplementedError("raw text needs the tokenizer stage, which runs before the accelerated "
+                                      "path; pass a tokenised Document")
+        doc = text  # a Document keeps its own sentence.lang_id (api.py:121-122)
+        del lang_id
+        self._lm_helper.apply(doc)
+        self._parser.process(doc, self._parser_collate, num_workers=0)
+        return doc
+
+
+def _load(lang: str, device: Optional[str] = "cpu", lm_helper=None) -> CubeObj:
+    try:
+        lang_path = os.path.join(str(Path.home()), ".nlpcube", "3.0", lang)
+        if not os.path.exists(lang_path):
+            raise FileNotFoundError(lang_path)
+        return CubeObj("{0}/{1}".format(lang_path, lang), device=device, lang=lang, lm_helper=lm_helper)
+    except Exception:
+        # one generic exception for every load failure, like the reference (api.py:193-200)
+        raise Exception("There was a problem retrieving this language: model files for '%s' are not available "
+                        "under ~/.nlpcube/3.0 (this build does not download models) or could not be loaded" % lang)
+
+
+class Cube:
+    """reference: cube/api.py:203-211"""
+
+    def __init__(self, verbose=False):
+        self._instance = None
+
+    def load(self, lang: str, device: Optional[str] = "cpu", lm_helper=None):
+        self._instance = _load(lang, device, lm_helper=lm_helper)
+
+    def __call__(self, text: Union[str, Document], flavour: Optional[str] = None):
+        return self._instance(text, flavour=flavour)

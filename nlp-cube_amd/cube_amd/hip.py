@@ -1,0 +1,103 @@
+"""ctypes binding of libcubehip.so (C ABI declared in include/cube_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There is no CPU
+fallback: if the shared object is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
+
+EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
+
+c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int), ("M", c_int), ("seq_len", c_int), ("taps", c_int), ("Kc", c_int),
+        ("W", c_void_p), ("N", c_int), ("bias", c_void_p),
+        ("epilogue", c_int), ("n_valid", c_int), ("accumulate", c_int),
+        ("out0", c_void_p), ("ldo0", c_int), ("col0", c_int),
+        ("rowmap", c_void_p),
+        ("res", c_void_p), ("ld_res", c_int), ("res_mode", c_int),
+        ("out1", c_void_p), ("ldo1", c_int), ("col1", c_int),
+        ("out2", c_void_p), ("ldo2", c_int), ("col2", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/cube_hip.h
+SIGNATURES = {
+    "cube_last_error": (ctypes.c_char_p, []),
+    "cube_abi_version": (c_int, []),
+    "cube_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    "cube_gather_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "cube_masked_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                c_int, c_void_p]),
+    "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cube_bilstm_recurrent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "cube_biaffine_arc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    "cube_mst_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cube_mst_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cube_label_score": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                 c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class CubeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CubeHipError("libcubehip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the parser path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        raise CubeHipError("%s failed (%d): %s" % (what, code, load().cube_last_error().decode("utf-8", "replace")))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
+         rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
+         a_col=0, stream=None):
+    """A/out*: torch tensors (device) or raw int pointers; a_col: starting column of A (bf16 elements)."""
+    a = GemmArgs()
+    a_ptr = A if isinstance(A, int) else A.data_ptr()
+    a.A = a_ptr + 2 * a_col
+    a.lda, a.M, a.seq_len, a.taps, a.Kc = lda, M, seq_len, taps, Kc
+    a.W, a.N, a.bias = ptr(W), N, ptr(bias)
+    a.epilogue, a.n_valid, a.accumulate = epilogue, n_valid, accumulate
+    a.out0, a.ldo0, a.col0 = ptr(out0), ldo0, col0
+    a.rowmap = ptr(rowmap)
+    a.res, a.ld_res, a.res_mode = ptr(res), ld_res, res_mode
+    a.out1, a.ldo1, a.col1 = ptr(out1), ldo1, col1
+    a.out2, a.ldo2, a.col2 = ptr(out2), ldo2, col2
+    check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")

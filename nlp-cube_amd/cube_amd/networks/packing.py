@@ -1,0 +1,287 @@
+"""Load-time weight packing for the HIP parser/tagger path.
+
+Turns a reference `state_dict` (key names of cube/networks/parser.py:23-95 and
+tagger.py:22-67) into the layouts the kernels read:
+
+* eval-mode BatchNorm1d folded into the conv weight/bias (modules.py:438-446), conv weights
+  re-laid as [N][tap*Kc + c] bf16 (n-major, K contiguous, Kc = channels padded to 32) with the
+  output channels permuted so that the tanh half and the sigmoid half of one channel land in
+  the same lane of the MFMA accumulator (`cube_gemm_bf16`, CUBE_EPI_GATE);
+* WordGram's `x = x + skip` doubling (modules.py:467-468) folded into the weights of char
+  layers >= 1 (exact: a power of two);
+* Linear weights zero-padded to [pad128(N)][pad32(K)], with input channels permuted where the
+  HIP path keeps a concat buffer in a different (16-byte aligned) column order than the
+  reference's torch.cat;
+* LSTM gate rows regrouped per 16 hidden units (i,f,g,o of one unit adjacent) and both biases
+  summed; biaffine weights transposed for the kernels; everything rounded to bf16 once.
+
+All arithmetic here is fp32 on the host; nothing in this file runs per batch.
+"""
+import numpy as np
+import torch
+
+
+def p32(x):
+    return (x + 31) // 32 * 32
+
+
+def p128(x):
+    return (x + 127) // 128 * 128
+
+
+def _bf16(t):
+    return t.to(torch.float32).contiguous().to(torch.bfloat16)
+
+
+def gate_column_order(half):
+    """packed column n -> original conv output channel (or -1 for padding)."""
+    nb = (half + 63) // 64
+    order = np.full(nb * 128, -1, dtype=np.int64)
+    for n in range(nb * 128):
+        b, r = divmod(n, 128)
+        wc, r = divmod(r, 64)
+        part, j = divmod(r, 32)
+        ch = b * 64 + wc * 32 + j
+        if ch < half:
+            order[n] = part * half + ch
+    return order
+
+
+def pack_gated_conv(sd, prefix, in_perm, double_first=0):
+    """-> dict(W bf16 [N, taps*Kc], bias f32 [N], Kc, N, half).
+    in_perm: for each column of the HIP activation buffer, the reference input channel (or -1)."""
+    w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
+    b = sd[prefix + ".0.conv.bias"].float()
+    s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
+    w = w * s[:, None, None]
+    b = (b - sd[prefix + ".1.running_mean"].float()) * s + sd[prefix + ".1.bias"].float()
+    F_, cin, taps = w.shape
+    half = F_ // 2
+    if double_first:
+        w = w.clone()
+        w[:, :double_first, :] *= 2.0
+    Kc = p32(len(in_perm))
+    order = gate_column_order(half)
+    N = len(order)
+    W = torch.zeros((N, taps, Kc), dtype=torch.float32)
+    bias = torch.zeros(N, dtype=torch.float32)
+    valid_n = torch.from_numpy(np.where(order >= 0)[0])
+    src_n = torch.from_numpy(order[order >= 0])
+    in_perm = np.asarray(in_perm)
+    valid_k = torch.from_numpy(np.where(in_perm >= 0)[0])
+    src_k = torch.from_numpy(in_perm[in_perm >= 0])
+    sub = w[src_n][:, src_k, :]  # [n, k, taps]
+    tmp = torch.zeros((len(valid_n), taps, Kc), dtype=torch.float32)
+    tmp[:, :, valid_k] = sub.permute(0, 2, 1)
+    W[valid_n] = tmp
+    bias[valid_n] = b[src_n]
+    return dict(W=_bf16(W.reshape(N, taps * Kc)), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
+
+
+def pack_linear(w, b, in_perm=None, out_rows=None, n_pad=None):
+    """w [n_out, n_in] -> W bf16 [pad128(rows), pad32(cols)], bias f32.
+    in_perm: buffer column -> reference input feature (-1 = zero column);
+    out_rows: packed output column -> reference output feature (-1 = zero row) or ('one',)."""
+    w = w.float()
+    n_out, n_in = w.shape
+    if in_perm is None:
+        in_perm = np.arange(n_in)
+    if out_rows is None:
+        out_rows = np.arange(n_out)
+    in_perm = np.asarray(in_perm)
+    out_rows = np.asarray(out_rows)
+    K = p32(len(in_perm))
+    N = n_pad or p128(len(out_rows))
+    W = torch.zeros((N, K), dtype=torch.float32)
+    bias = torch.zeros(N, dtype=torch.float32)
+    vn = np.where(out_rows >= 0)[0]
+    vk = np.where(in_perm >= 0)[0]
+    tmp = torch.zeros((len(vn), K), dtype=torch.float32)
+    tmp[:, torch.from_numpy(vk)] = w[torch.from_numpy(out_rows[vn])][:, torch.from_numpy(in_perm[vk])]
+    W[torch.from_numpy(vn)] = tmp
+    if b is not None:
+        bias[torch.from_numpy(vn)] = b.float()[torch.from_numpy(out_rows[vn])]
+    return dict(W=_bf16(W), bias=bias.contiguous(), K=K, N=N, n_valid=len(out_rows))
+
+
+def pack_table(t, width=None):
+    """embedding table -> bf16 [rows, width] (width >= cols, zero padded)."""
+    t = t.float()
+    width = width or t.shape[1]
+    out = torch.zeros((t.shape[0], width), dtype=torch.float32)
+    out[:, :t.shape[1]] = t
+    return _bf16(out)
+
+
+class Layout:
+    """Column layouts of the activation buffers (all offsets in bf16 elements)."""
+
+    def __init__(self, cfg, n_ext, is_parser=True):
+        self.char_emb, self.case_emb, self.lang = cfg.char_emb_size, 32, cfg.lang_emb_size
+        self.char_half, self.word_half = cfg.char_filter_size // 2, cfg.cnn_filter // 2
+        self.word_emb, self.P = cfg.word_emb_size, cfg.external_proj_size
+        # XC0: [tok | case | lang]  (reference order, modules.py:455,470)
+        self.xc0_w = p32(self.char_emb + self.case_emb + self.lang)
+        self.xc0_lang = self.char_emb + self.case_emb
+        # XC (layers >= 1): [g | lang]
+        self.xc_w = p32(self.char_half + self.lang)
+        # XW0: [word | char | lang | ext]   (reference: word, char, ext, lang — parser.py:149-151)
+        self.xw0_char = self.word_emb
+        self.xw0_lang = self.word_emb + self.char_half
+        self.xw0_ext = self.xw0_lang + self.lang
+        self.xw0_n = self.xw0_ext + self.P
+        self.xw0_w = p32(self.xw0_n)
+        self.xw_w = p32(self.word_half + self.lang)  # [g | lang]
+
+    def xw0_perm(self):
+        """buffer column -> reference channel of the first word-level conv / of `_r_emb`."""
+        ref_word, ref_char = 0, self.word_emb
+        ref_ext = ref_char + self.char_half
+        ref_lang = ref_ext + self.P
+        perm = list(range(ref_word, ref_word + self.word_emb)) + list(range(ref_char, ref_char + self.char_half))
+        perm += list(range(ref_lang, ref_lang + self.lang)) + list(range(ref_ext, ref_ext + self.P))
+        return np.asarray(perm)
+
+
+def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
+    """Pieces shared by Parser and Tagger: WordGram, ext MLPs, word-level conv stack, aux heads."""
+    pk = {}
+    pk["tok_emb"] = pack_table(sd["_word_net._tok_emb.weight"])
+    pk["case_emb"] = pack_table(sd["_word_net._case_emb.weight"])
+    pk["wn_lang_emb"] = pack_table(sd["_word_net._lang_emb.weight"])
+    c0 = lay.char_emb + lay.case_emb + lay.lang
+    pk["char_convs"] = []
+    for l in range(cfg.char_layers):
+        cin = c0 if l == 0 else lay.char_half + lay.lang
+        pk["char_convs"].append(pack_gated_conv(sd, "_word_net._convolutions_char.%d" % l, np.arange(cin),
+                                                double_first=lay.char_half if l > 0 else 0))
+    pk["char_pre_out"] = pack_linear(sd["_word_net._pre_out.linear_layer.weight"], sd["_word_net._pre_out.linear_layer.bias"])
+    pk["ext"] = []
+    for i, e in enumerate(ext_dims):
+        h1 = pack_linear(sd["_ext_proj.%d._h1.linear_layer.weight" % i], sd["_ext_proj.%d._h1.linear_layer.bias" % i])
+        hid = sd["_ext_proj.%d._h2.linear_layer.weight" % i].shape[1]
+        h2 = pack_linear(sd["_ext_proj.%d._h2.linear_layer.weight" % i], sd["_ext_proj.%d._h2.linear_layer.bias" % i],
+                         in_perm=np.concatenate([np.arange(hid), -np.ones(h1["N"] - hid, dtype=np.int64)]))
+        pk["ext"].append(dict(h1=h1, h2=h2, E=e, Epad=p32(e)))
+    pk["word_emb"] = pack_table(sd["_word_emb.weight"])
+    pk["lang_emb"] = pack_table(sd["_lang_emb.weight"])
+    perm0 = lay.xw0_perm()
+    pk["word_convs"] = []
+    for l in range(cfg.cnn_layers):
+        perm = perm0 if l == 0 else np.arange(lay.word_half + lay.lang)
+        pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, perm))
+    # aux heads read [char_emb | lang], contiguous inside XW0
+    n_u, n_x, n_a = enc_sizes["upos"], enc_sizes["xpos"], enc_sizes["attrs"]
+    w = torch.cat([sd["_aupos.linear_layer.weight"], sd["_axpos.linear_layer.weight"], sd["_aattrs.linear_layer.weight"]], 0)
+    b = torch.cat([sd["_aupos.linear_layer.bias"], sd["_axpos.linear_layer.bias"], sd["_aattrs.linear_layer.bias"]], 0)
+    pk["aux"] = pack_linear(w, b)
+    return pk
+
+
+def lstm_gate_rows(H):
+    """packed gate column (within one direction) -> reference row g*H + hid, or -1."""
+    U = (H + 15) // 16
+    rows = np.full(U * 64, -1, dtype=np.int64)
+    for u in range(U):
+        for g in range(4):
+            for j in range(16):
+                hid = u * 16 + j
+                if hid < H:
+                    rows[u * 64 + g * 16 + j] = g * H + hid
+    return rows
+
+
+def pack_parser(sd, cfg, enc_sizes, ext_dims):
+    """-> (dict of packed CPU tensors / ints, Layout)."""
+    lay = Layout(cfg, len(ext_dims))
+    pk = pack_front(sd, cfg, enc_sizes, ext_dims, lay)
+    half, L_, P, H = lay.word_half, lay.lang, lay.P, cfg.rnn_size
+    n_u, n_x, n_a, n_l = enc_sizes["upos"], enc_sizes["xpos"], enc_sizes["attrs"], enc_sizes["labels"]
+    pk["r_emb"] = pack_table(sd["_r_emb.weight"][:, torch.from_numpy(lay.xw0_perm())], lay.xw0_w)
+    # morphology: XM = [hidden | lang];  PM = [pre_morpho | lang | upos_emb]
+    pk["pre_morpho"] = pack_linear(sd["_pre_morpho.linear_layer.weight"], sd["_pre_morpho.linear_layer.bias"])
+    pk["upos"] = pack_linear(sd["_upos.linear_layer.weight"], sd["_upos.linear_layer.bias"])
+    w = torch.cat([sd["_attrs.linear_layer.weight"], sd["_xpos.linear_layer.weight"]], 0)
+    b = torch.cat([sd["_attrs.linear_layer.bias"], sd["_xpos.linear_layer.bias"]], 0)
+    pk["attrs_xpos"] = pack_linear(w, b)
+    pk["upos_emb"] = pack_table(sd["_upos_emb.weight"])
+    # LSTM.  XL0 = [x_parse | lang | ext] (reference: x_parse, ext, lang — parser.py:195-200)
+    rows1 = lstm_gate_rows(H)
+    G = len(rows1)
+    pk["lstm"] = []
+    for l in range(cfg.rnn_layers):
+        if l == 0:
+            in_perm = np.concatenate([np.arange(half), half + P + np.arange(L_), half + np.arange(P)])
+        else:
+            in_perm = np.arange(2 * H)
+        ws, bs, hh = [], [], []
+        for suffix in ("", "_reverse"):
+            ws.append(sd["_rnn.weight_ih_l%d%s" % (l, suffix)].float())
+            bs.append(sd["_rnn.bias_ih_l%d%s" % (l, suffix)].float() + sd["_rnn.bias_hh_l%d%s" % (l, suffix)].float())
+            whh = sd["_rnn.weight_hh_l%d%s" % (l, suffix)].float()
+            KH = p32(H)
+            wp = torch.zeros((G, KH), dtype=torch.float32)
+            v = np.where(rows1 >= 0)[0]
+            wp[torch.from_numpy(v), :H] = whh[torch.from_numpy(rows1[v])]
+            hh.append(wp)
+        out_rows = np.concatenate([rows1, np.where(rows1 >= 0, rows1 + 4 * H, -1)])
+        ih = pack_linear(torch.cat(ws, 0), torch.cat(bs, 0), in_perm=in_perm, out_rows=out_rows)
+        pk["lstm"].append(dict(ih=ih, whh=_bf16(torch.stack(hh, 0)), G=G))
+    # _pre_out reads [h_fwd | h_bwd | lang]  (reference order)
+    pk["pre_out"] = pack_linear(sd["_pre_out.linear_layer.weight"], sd["_pre_out.linear_layer.bias"])
+    pp_w = pk["pre_out"]["N"]  # width of the pre_parsing buffer (pad columns are tanh(0) = 0)
+    pp_perm = np.concatenate([np.arange(cfg.pre_parser_size), -np.ones(pp_w - cfg.pre_parser_size, dtype=np.int64)])
+
+    def biaffine_in(name, hs):
+        """[h1 | 1 | 0.. | h2 | 1 | 0..] with D = pad32(hs+1) columns each; ones via relu(0*x + 1)."""
+        D = p32(hs + 1)
+        w = torch.cat([sd[name + ".W1.weight"], sd[name + ".W2.weight"]], 0).float()
+        b = torch.cat([sd[name + ".W1.bias"], sd[name + ".W2.bias"]], 0).float()
+        out_rows = -np.ones(2 * D, dtype=np.int64)
+        out_rows[:hs] = np.arange(hs)
+        out_rows[D:D + hs] = hs + np.arange(hs)
+        p = pack_linear(w, b, in_perm=pp_perm, out_rows=out_rows)
+        p["bias"][hs] = 1.0
+        p["bias"][D + hs] = 1.0
+        p["D"] = D
+        return p
+
+    hs, ls = cfg.head_size, cfg.label_size
+    pk["head_in"] = biaffine_in("_head", hs)
+    Dh = pk["head_in"]["D"]
+    wb = sd["_head.scorer.W_bilin.weight"].float()[:, :, 0]  # [p, q]
+    wpad = torch.zeros((Dh, Dh), dtype=torch.float32)
+    wpad[:hs + 1, :hs + 1] = wb.t()  # packed [q][p]
+    pk["head_bilin"] = dict(W=_bf16(torch.cat([wpad, torch.zeros((p128(Dh) - Dh, Dh))], 0)), N=p128(Dh), K=Dh)
+    pk["label_in"] = biaffine_in("_label", ls)
+    Dl = pk["label_in"]["D"]
+    wl = sd["_label.scorer.W_bilin.weight"].float()  # [o, p, q]
+    wlp = torch.zeros((n_l, Dl, Dl), dtype=torch.float32)
+    wlp[:, :ls + 1, :ls + 1] = wl.permute(0, 2, 1)  # [o][q][p]
+    pk["label_bilin"] = dict(W=_bf16(wlp), bias=sd["_label.scorer.W_bilin.bias"].float().contiguous(), D=Dl)
+    return pk, lay
+
+
+def pack_tagger(sd, cfg, enc_sizes, ext_dims):
+    lay = Layout(cfg, len(ext_dims), is_parser=False)
+    pk = pack_front(sd, cfg, enc_sizes, ext_dims, lay)
+    half, L_ = lay.word_half, lay.lang
+    # TU = [x+res | lang | upos_emb]; reference: upos reads [x, lang], xpos/attrs read
+    # [upos_emb, lang, x]  (tagger.py:148-161)
+    pk["upos"] = pack_linear(sd["_upos.linear_layer.weight"], sd["_upos.linear_layer.bias"])
+    perm = np.concatenate([64 + L_ + np.arange(half), 64 + np.arange(L_), np.arange(64)])
+    w = torch.cat([sd["_attrs.linear_layer.weight"], sd["_xpos.linear_layer.weight"]], 0)
+    b = torch.cat([sd["_attrs.linear_layer.bias"], sd["_xpos.linear_layer.bias"]], 0)
+    pk["attrs_xpos"] = pack_linear(w, b, in_perm=perm)
+    pk["upos_emb"] = pack_table(sd["_upos_emb.weight"])
+    return pk, lay
+
+
+def to_device(obj, device):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [to_device(v, device) for v in obj]
+    return obj

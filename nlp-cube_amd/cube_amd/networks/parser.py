@@ -1,0 +1,387 @@
+"""MI355X-native joint tagger + dependency parser (inference).
+
+Host-side mirror of the reference `Parser` (cube/networks/parser.py:22-95, 109-233,
+400-448): same constructor, `load`, `to`, `forward`, `_get_labels` and `process` signatures
+and results, but every tensor operation of the path runs in hand-written gfx950 kernels
+behind the C ABI of include/cube_hip.h (bf16 MFMA operands, fp32 accumulation; the
+arithmetic contract is restated by oracle/parser_oracle.py, quant="bf16").
+
+Per batch: 1 upload of int32 indices + bf16 external embeddings, ~45 asynchronous kernel
+launches on the current HIP stream, 1 download of five int32 arrays — the reference's three
+mid-batch syncs (parser.py:125, 425, 428-431) are gone because unpack, soft-max, MST decoding
+and the head gather for label scoring all stay on the device.
+"""
+import numpy as np
+import torch
+
+from cube_amd import hip
+from cube_amd.networks import packing
+from cube_amd.networks.packing import p32, p128
+from cube_amd.networks.utils import MorphoCollate, MorphoDataset, ChuLiuEdmondsDecoder  # noqa: F401
+
+
+class _Buffers:
+    """Grow-only, zero-initialised flat device buffers with fixed leading dimensions, so the
+    padding columns no kernel writes stay zero for the life of the model."""
+
+    def __init__(self, device):
+        self.device = device
+        self._b = {}
+
+    def get(self, name, rows, ld, dtype=torch.bfloat16):
+        need = rows * ld
+        t = self._b.get(name)
+        if t is None or t.numel() < need or t.dtype != dtype:
+            t = torch.zeros(max(need, 1), dtype=dtype, device=self.device)
+            self._b[name] = t
+        return t
+
+
+class Parser:
+    def __init__(self, config, encodings, language_codes=None, ext_word_emb=0):
+        self._config = config
+        self._encodings = encodings
+        if not isinstance(ext_word_emb, (list, tuple)):
+            ext_word_emb = [ext_word_emb]
+        self._ext_word_emb = list(ext_word_emb)
+        self._num_langs = encodings.num_langs
+        self._language_codes = language_codes
+        self._decoder = ChuLiuEdmondsDecoder()
+        self._device = torch.device("cpu")
+        self._pk_cpu = None
+        self._pk = None
+        self._lay = None
+        self._buf = None
+        self.training = False
+
+    # ---- reference-compatible module surface ----------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        enc = self._encodings
+        sizes = dict(upos=len(enc.upos2int), xpos=len(enc.xpos2int), attrs=len(enc.attrs2int),
+                     labels=len(enc.label2int))
+        self._sizes = sizes
+        self._pk_cpu, self._lay = packing.pack_parser(state_dict, self._config, sizes, self._ext_word_emb)
+        self._pk = None
+        if self._device.type == "cuda":
+            self.to(self._device)
+
+    def load(self, model_path, device="cpu"):
+        """reference: parser.py:400-402 (Lightning checkpoint, only ['state_dict'] is read)."""
+        ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+        self.load_state_dict(ckpt["state_dict"])
+        self.to(device)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            # the reference defaults to 'cpu'; this implementation has no CPU path
+            self._device = device
+            return self
+        hip.load()
+        self._device = device
+        if self._pk_cpu is not None:
+            self._pk = packing.to_device(self._pk_cpu, device)
+            self._buf = _Buffers(device)
+        return self
+
+    def _require_gpu(self):
+        if self._pk is None or self._device.type != "cuda":
+            raise hip.CubeHipError("cube_amd Parser runs only on an MI355X: load weights and call .to('cuda:N') "
+                                   "(there is no CPU fallback)")
+
+    # ---- batch preparation -----------------------------------------------------------------
+    def _prepare(self, X):
+        """reference-format batch dict (MorphoCollate.collate_fn) -> device index arrays.
+        One packed int32 upload + one bf16 upload per LM layer."""
+        dev = self._device
+        x_sent = X["x_sent"].cpu().numpy()
+        sl = X["x_sent_len"].cpu().numpy().astype(np.int64)
+        x_word = X["x_word"].cpu().numpy()
+        B, L = x_sent.shape
+        N, W = x_word.shape
+        T = L + 1
+        lang_sent = X["x_lang_sent"].cpu().numpy()
+        sb = np.repeat(np.arange(B), sl)
+        si = np.arange(N) - np.repeat(np.cumsum(sl) - sl, sl)
+        word_idx = np.zeros((B, T), dtype=np.int32)
+        word_idx[:, 1:] = x_sent
+        parts = [
+            x_word.reshape(-1), X["x_word_case"].cpu().numpy().reshape(-1),
+            np.repeat(X["x_lang_word"].cpu().numpy(), W), X["x_word_len"].cpu().numpy(),
+            sb * T + si + 1, word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
+        ]
+        sizes = [p.size for p in parts]
+        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
+        packed = np.zeros(int(offs[-1]), dtype=np.int32)
+        for p, o, s in zip(parts, offs[:-1], sizes):
+            packed[o:o + s] = p
+        ints = torch.from_numpy(packed).to(dev, non_blocking=True)
+        names = ("char_idx", "case_idx", "lang_char", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
+                 "lens")
+        bt = {n: ints[o:o + s] for n, o, s in zip(names, offs[:-1], sizes)}
+        embs = []
+        for k, e in enumerate(X["x_word_embeddings"]):
+            ek = self._pk["ext"][k]
+            pad = torch.zeros((B, L, ek["Epad"]), dtype=torch.bfloat16)
+            pad.view(B * L, -1)[torch.from_numpy(sb * L + si), :ek["E"]] = e.cpu().to(torch.bfloat16)
+            embs.append(pad.to(dev, non_blocking=True))
+        bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs)
+        if "y_upos" in X:
+            bt["y_upos"] = X["y_upos"].to(dev).to(torch.int32).contiguous()
+        return bt
+
+    # ---- the device pipeline ---------------------------------------------------------------
+    def _encode(self, bt, want_aux=False):
+        """Runs char-CNN, ext MLPs, word-CNN, morphology heads, BiLSTM, pre_parsing and the arc
+        scorer.  Returns a dict of device tensors (views into the workspace)."""
+        self._require_gpu()
+        lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
+        st = hip.stream_handle()
+        B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
+        NW, BT, BL = N * W, B * T, B * L
+        ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
+        H = cfg.rnn_size
+
+        def gather(dst, ld, col0, width, table, idx, rows, n):
+            hip.check(lib.cube_gather_rows(dst.data_ptr(), ld, col0, width, table.data_ptr(), table.shape[1],
+                                           hip.ptr(idx), hip.ptr(rows), n, st), "cube_gather_rows")
+
+        # ---- character level (WordGram, modules.py:450-484)
+        xc0 = buf.get("xc0", NW, lay.xc0_w)
+        xca, xcb = buf.get("xca", NW, lay.xc_w), buf.get("xcb", NW, lay.xc_w)
+        resc = buf.get("resc", NW, ch, torch.float32)
+        gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, NW)
+        gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, NW)
+        gather(xc0, lay.xc0_w, lay.xc0_lang, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
+        nchar = len(pk["char_convs"])
+        if nchar > 1:
+            gather(xca, lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
+        if nchar > 2:
+            gather(xcb, lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
+        src, src_ld = xc0, lay.xc0_w
+        for l, cv in enumerate(pk["char_convs"]):
+            last = l == nchar - 1
+            dst = None if last else (xca if l % 2 == 0 else xcb)
+            hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xc_w,
+                     col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], res=resc, ld_res=ch,
+                     res_mode=(0 if l == 0 else (2 if last else 1)) if nchar > 1 else 0, stream=st)
+            src, src_ld = dst, lay.xc_w
+        if nchar == 1:
+            # single layer: x + res = 2 g; fold by a second accumulation pass is not needed: res_mode 0 wrote g
+            resc.mul_(2.0)
+        pool_w = p32(ch)
+        pool = buf.get("pool", N, pool_w)
+        hip.check(lib.cube_masked_mean(resc.data_ptr(), ch, bt["word_len"].data_ptr(), N, W, ch, pool.data_ptr(), pool_w,
+                                       st), "cube_masked_mean")
+        # ---- word level input XW0 = [word | char | lang | ext], root row = _r_emb
+        xw0 = buf.get("xw0", BT, lay.xw0_w)
+        xw0[:BT * lay.xw0_w].zero_()
+        gather(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT)
+        po = pk["char_pre_out"]
+        hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
+                 col0=lay.xw0_char, n_valid=ch, rowmap=bt["rowmap_word"], stream=st)
+        gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138)
+        xl0_w = p32(wh + lg + P)
+        xl0 = buf.get("xl0", BT, xl0_w)
+        xl0[:BT * xl0_w].zero_()
+        ext_h = buf.get("ext_h", BL, pk["ext"][0]["h1"]["N"])
+        ext_acc = buf.get("ext_acc", BL, 8 * ((P + 7) // 8), torch.float32)
+        ld_acc = 8 * ((P + 7) // 8)
+        for k, ek in enumerate(pk["ext"]):
+            h1, h2 = ek["h1"], ek["h2"]
+            hip.gemm(bt["embs"][k], ek["Epad"], BL, h1["K"], h1["W"], h1["N"], h1["bias"], hip.EPI_BF16_TANH,
+                     out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
+            hip.gemm(ext_h, h1["N"], BL, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
+                     n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
+        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, P, len(pk["ext"]), xw0.data_ptr(), lay.xw0_w,
+                                      lay.xw0_ext, xl0.data_ptr(), xl0_w, wh + lg, st), "cube_ext_finish")
+        gather(xw0, lay.xw0_w, 0, lay.xw0_w, pk["r_emb"], None, bt["root_rows"], B)
+        out = {}
+        if want_aux:
+            ax = pk["aux"]
+            aux = torch.empty((BT, ax["n_valid"]), dtype=torch.float32, device=self._device)
+            hip.gemm(xw0, lay.xw0_w, BT, ax["K"], ax["W"], ax["N"], ax["bias"], hip.EPI_F32, out0=aux,
+                     ldo0=ax["n_valid"], n_valid=ax["n_valid"], a_col=lay.xw0_char, stream=st)
+            out["aux"] = aux
+        # ---- word-level gated CNN (parser.py:157-176)
+        xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
+        resw = buf.get("resw", BT, wh, torch.float32)
+        xm_w = p32(wh + lg)
+        xm = buf.get("xm", BT, xm_w)
+        gather(xwa, lay.xw_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        gather(xwb, lay.xw_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        gather(xm, xm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        gather(xl0, xl0_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        nword = len(pk["word_convs"])
+        src, src_ld = xw0, lay.xw0_w
+        for l, cv in enumerate(pk["word_convs"]):
+            last = l == nword - 1
+            dst = None if last else (xwa if l % 2 == 0 else xwb)
+            aux_here = (l + 1 == cfg.aux_softmax_location)
+            o1, o2 = (xm if aux_here else None), (xl0 if last else None)
+            hip.gemm(src, src_ld, BT, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
+                     col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh,
+                     res_mode=0 if l == 0 else 1, out1=o1, ldo1=xm_w, col1=0, out2=o2, ldo2=xl0_w, col2=0, stream=st)
+            src, src_ld = dst, lay.xw_w
+        # ---- morphology heads (parser.py:178-192); PM = [pre_morpho | lang | upos_emb]
+        pm_w = p32(wh + lg + 64)
+        pm = buf.get("pm", BT, pm_w)
+        gather(pm, pm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        q = pk["pre_morpho"]
+        hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
+                 n_valid=q["n_valid"], stream=st)
+        n_u = self._sizes["upos"]
+        upos_log = torch.empty((BT, n_u), dtype=torch.float32, device=self._device)
+        q = pk["upos"]
+        hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=upos_log, ldo0=n_u, n_valid=n_u,
+                 stream=st)
+        upos_idx = torch.empty((BT,), dtype=torch.int32, device=self._device)
+        hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, upos_idx.data_ptr(), st), "cube_argmax_rows")
+        emb_idx = upos_idx
+        if "y_upos" in bt:  # gold tags given (training-time behaviour of forward, parser.py:185-188)
+            emb_idx = torch.zeros((B, T), dtype=torch.int32, device=self._device)
+            emb_idx[:, 1:] = bt["y_upos"]
+            emb_idx = emb_idx.view(-1)
+        gather(pm, pm_w, wh + lg, 64, pk["upos_emb"], emb_idx, None, BT)
+        q = pk["attrs_xpos"]
+        n_ax = q["n_valid"]
+        ax_log = torch.empty((BT, n_ax), dtype=torch.float32, device=self._device)
+        hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
+                 stream=st)
+        # ---- BiLSTM (parser.py:194-202): per layer one projection GEMM + one persistent recurrent kernel
+        xl_w = p32(2 * H + lg)
+        xla, xlb = buf.get("xla", BT, xl_w), buf.get("xlb", BT, xl_w)
+        gather(xla, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        gather(xlb, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        G2 = 2 * pk["lstm"][0]["G"]
+        gx = buf.get("gx", BT, G2, torch.float32)
+        src, src_ld = xl0, xl0_w
+        for l, ly in enumerate(pk["lstm"]):
+            ih = ly["ih"]
+            dst = xla if l % 2 == 0 else xlb
+            hip.gemm(src, src_ld, BT, ih["K"], ih["W"], ih["N"], ih["bias"], hip.EPI_F32, out0=gx, ldo0=G2, n_valid=G2,
+                     stream=st)
+            hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].data_ptr(), B, T, H, dst.data_ptr(), xl_w, 0,
+                                                st), "cube_bilstm_recurrent")
+            src, src_ld = dst, xl_w
+        # ---- pre_parsing (parser.py:202-203) and the arc scorer (modules.py:518-533, 550-579)
+        q = pk["pre_out"]
+        pp_w = q["N"]
+        pp = buf.get("pp", BT, pp_w)
+        hip.gemm(src, src_ld, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pp, ldo0=pp_w,
+                 n_valid=q["n_valid"], stream=st)
+        q = pk["head_in"]
+        Dh = q["D"]
+        ha = buf.get("ha", BT, 2 * Dh)
+        hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=ha, ldo0=2 * Dh,
+                 n_valid=2 * Dh, stream=st)
+        q = pk["head_bilin"]
+        u = buf.get("u", BT, Dh)
+        hip.gemm(ha, 2 * Dh, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
+        arc_logits = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
+        arc_probs = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
+        hip.check(lib.cube_biaffine_arc(u.data_ptr(), Dh, ha.data_ptr(), 2 * Dh, Dh, Dh, B, T, arc_logits.data_ptr(),
+                                        arc_probs.data_ptr(), st), "cube_biaffine_arc")
+        out.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w,
+                   upos_logits=upos_log.view(B, T, n_u)[:, 1:, :], upos_idx=upos_idx.view(B, T)[:, 1:],
+                   ax_logits=ax_log.view(B, T, n_ax)[:, 1:, :], ax_all=ax_log)
+        return out
+
+    def _label_scores(self, bt, pp, pp_w, heads_dev):
+        """parser.py:218-233: gather head rows + DeepBiaffine(pairwise=False), fused on device."""
+        lib, pk, st = hip.load(), self._pk, hip.stream_handle()
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        BT = B * T
+        q = pk["label_in"]
+        Dl = q["D"]
+        hl = self._buf.get("hl", BT, 2 * Dl)
+        hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hl, ldo0=2 * Dl,
+                 n_valid=2 * Dl, stream=st)
+        n_l = self._sizes["labels"]
+        logits = torch.empty((B, L, n_l), dtype=torch.float32, device=self._device)
+        labels = torch.empty((B, L), dtype=torch.int32, device=self._device)
+        lb = pk["label_bilin"]
+        hip.check(lib.cube_label_score(hl.data_ptr(), 2 * Dl, Dl, Dl, lb["W"].data_ptr(), lb["bias"].data_ptr(), n_l,
+                                       heads_dev.data_ptr(), bt["lens"].data_ptr(), B, L, logits.data_ptr(),
+                                       labels.data_ptr(), st), "cube_label_score")
+        return logits, labels
+
+    # ---- reference API ---------------------------------------------------------------------
+    def forward(self, X):
+        """reference: parser.py:109-216.  Returns (arc logits [B,L,T], pre_parsing [B,T,pre],
+        upos, xpos, attrs, aupos, axpos, aattrs) as float32 device tensors."""
+        bt = self._prepare(X)
+        self._last_bt = bt
+        r = self._encode(bt, want_aux=True)
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        n_u, n_x, n_a = self._sizes["upos"], self._sizes["xpos"], self._sizes["attrs"]
+        pre = r["pp"][:B * T * r["pp_w"]].view(B, T, r["pp_w"])[:, :, :self._config.pre_parser_size].float()
+        attrs, xpos = r["ax_logits"][:, :, :n_a], r["ax_logits"][:, :, n_a:n_a + n_x]
+        aux = r["aux"].view(B, T, -1)[:, 1:, :]
+        return (r["arc_logits"], pre, r["upos_logits"], xpos, attrs, aux[:, :, :n_u], aux[:, :, n_u:n_u + n_x],
+                aux[:, :, n_u + n_x:n_u + n_x + n_a])
+
+    def _get_labels(self, labels, heads):
+        """reference: parser.py:218-233.  `labels` = pre_parsing as returned by forward (the
+        batch it came from must be the last one given to forward), `heads` = list of arrays."""
+        bt = self._last_bt
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        hp = np.zeros((B, L), dtype=np.int32)
+        for b, h in enumerate(heads):
+            hp[b, :len(h)] = np.asarray(h)
+        pp_w = self._pk["pre_out"]["N"]
+        pp = self._buf.get("pp_ext", B * T, pp_w)
+        pp[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = labels.to(self._device).to(torch.bfloat16)
+        logits, _ = self._label_scores(bt, pp, pp_w, torch.from_numpy(hp).to(self._device))
+        return logits
+
+    def decode_batch(self, X):
+        """One batch of `process` on the device: everything up to the five int32 result arrays."""
+        bt = self._prepare(X)
+        r = self._encode(bt)
+        heads, status = self._decoder.decode_device(r["arc_probs"], bt["lens"])
+        label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], heads)
+        lib, st = hip.load(), hip.stream_handle()
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        n_x, n_a = self._sizes["xpos"], self._sizes["attrs"]
+        n_ax = n_a + n_x
+        ax_idx = torch.empty((2, B * T), dtype=torch.int32, device=self._device)
+        hip.check(lib.cube_argmax_rows(r["ax_all"].data_ptr(), n_ax, 0, n_a, B * T, ax_idx[0].data_ptr(), st), "argmax")
+        hip.check(lib.cube_argmax_rows(r["ax_all"].data_ptr(), n_ax, n_a, n_x, B * T, ax_idx[1].data_ptr(), st), "argmax")
+        r.update(heads=heads, status=status, label_logits=label_logits, labels=labels,
+                 upos=r["upos_idx"], attrs=ax_idx[0].view(B, T)[:, 1:], xpos=ax_idx[1].view(B, T)[:, 1:], bt=bt)
+        return r
+
+    def process(self, doc, collate, batch_size=4, num_workers=4):
+        """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
+        head/label/upos/xpos/attrs of every word of `doc` and returns it."""
+        self.eval()
+        self._require_gpu()
+        enc = self._encodings
+        sents = doc.sentences
+        for start in range(0, len(sents), batch_size):
+            batch = sents[start:start + batch_size]
+            X = collate.collate_fn(batch)
+            X.pop("y_upos", None)
+            r = self.decode_batch(X)
+            B, L = r["bt"]["B"], r["bt"]["L"]
+            res = torch.stack([r["heads"], r["labels"], r["upos"].contiguous(), r["xpos"].contiguous(),
+                               r["attrs"].contiguous()]).cpu().numpy()
+            status = r["status"].cpu().numpy()
+            if (status != 0).any():
+                raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
+                                     % (start + np.where(status != 0)[0]).tolist())
+            heads = res[0].astype(np.int64)
+            for b, s in enumerate(batch):
+                for i, w in enumerate(s.words):
+                    w.head = heads[b, i]
+                    w.label = enc.labels[res[1, b, i]]
+                    w.upos = enc.upos_list[res[2, b, i]]
+                    w.xpos = enc.xpos_list[res[3, b, i]]
+                    w.attrs = enc.attrs_list[res[4, b, i]]
+        return doc

@@ -1,0 +1,128 @@
+"""CPU tests of the host side: featurisation against the reference's golden collate output,
+data-model round trips, weight packing invariants, and that the C-ABI library loads and exports
+every symbol include/cube_hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from cube_amd import hip, synth
+from cube_amd.io_utils.config import ParserConfig
+from cube_amd.io_utils.encodings import Encodings
+from cube_amd.io_utils.objects import Document
+from cube_amd.networks import packing
+from cube_amd.networks.utils import MorphoCollate, unpack
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_collate_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_collate.npz"))
+    _, enc, _ = cases.parser_model(cases.TINY)
+    doc = cases.document(cases.TINY, enc, "g1")
+    out = MorphoCollate(enc).collate_fn(doc.sentences)
+    for k in ("x_sent", "x_lang_sent", "x_word", "x_word_case", "x_lang_word", "x_sent_len", "x_word_len",
+              "x_sent_masks", "x_word_masks"):
+        assert out[k].numpy().dtype == g[k].dtype, k
+        np.testing.assert_array_equal(out[k].numpy(), g[k], err_msg=k)
+    for i, e in enumerate(out["x_word_embeddings"]):
+        np.testing.assert_array_equal(e.numpy(), g["emb%d" % i])
+    assert set(out) >= {"y_upos", "y_xpos", "y_attrs"}
+
+
+def test_unpack_matches_reference_semantics():
+    data = torch.arange(12, dtype=torch.float32).view(6, 2)
+    out = unpack(data, [2, 0, 3, 1], 4)
+    assert out.shape == (4, 4, 2)
+    np.testing.assert_array_equal(out[0, :2].numpy(), data[:2].numpy())
+    assert (out[1] == 0).all() and (out[0, 2:] == 0).all()
+    np.testing.assert_array_equal(out[2, :3].numpy(), data[2:5].numpy())
+
+
+def test_encodings_and_config_round_trip(tmp_path):
+    enc = synth.make_encodings(n_chars=40, n_words=50, n_upos=6, n_xpos=7, n_attrs=8, n_labels=9, num_langs=3)
+    f = str(tmp_path / "x.encodings")
+    enc.save(f)
+    e2 = Encodings()
+    e2.load(f)
+    assert e2.num_langs == 3 and e2.char2int == enc.char2int and e2.word2int == enc.word2int
+    assert e2.labels == enc.labels and e2.upos_list == enc.upos_list and e2.attrs_list == enc.attrs_list
+    cfg = ParserConfig()
+    cfg.rnn_size = 123
+    cfg.lm_model = "dummy:x"
+    c = str(tmp_path / "p.config")
+    cfg.save(c)
+    c2 = ParserConfig(filename=c)
+    assert c2.rnn_size == 123 and c2.lm_model == "dummy:x" and c2.char_layers == 5
+
+
+def test_document_conllu_round_trip(tmp_path, golden_dir):
+    src = os.path.join(golden_dir, "g6_process_tiny_bs4.conllu")
+    text = open(src, encoding="utf-8").read()
+    f = tmp_path / "d.conllu"
+    f.write_text(text + "\n\n", encoding="utf-8")
+    doc = Document(filename=str(f), lang_id=2)
+    assert str(doc) == text
+    assert all(s.lang_id == 2 for s in doc.sentences) and len(doc.sentences) == 32
+    assert isinstance(doc.sentences[0].words[0].head, int)
+
+
+def test_gate_packing_is_a_permutation():
+    for half in (16, 64, 256):
+        order = packing.gate_column_order(half)
+        valid = order[order >= 0]
+        assert sorted(valid.tolist()) == list(range(2 * half))
+        # tanh and sigmoid halves of one channel sit 32 columns apart inside a 64-column wave tile
+        pos = {int(c): n for n, c in enumerate(order) if c >= 0}
+        for ch in range(half):
+            assert pos[half + ch] - pos[ch] == 32 and pos[ch] % 64 < 32
+
+
+def test_pack_parser_shapes():
+    cfg, enc, sd = cases.parser_model(cases.TINY)
+    sizes = dict(upos=len(enc.upos2int), xpos=len(enc.xpos2int), attrs=len(enc.attrs2int), labels=len(enc.label2int))
+    pk, lay = packing.pack_parser(sd, cfg, sizes, list(cases.TINY["ext"]))
+    for cv in pk["char_convs"] + pk["word_convs"]:
+        assert cv["W"].shape == (cv["N"], cv["taps"] * cv["Kc"]) and cv["N"] % 128 == 0 and cv["Kc"] % 32 == 0
+        assert cv["W"].dtype == torch.bfloat16
+    rows = packing.lstm_gate_rows(cfg.rnn_size)
+    assert sorted(rows[rows >= 0].tolist()) == list(range(4 * cfg.rnn_size))
+    assert pk["lstm"][0]["whh"].shape == (2, len(rows), packing.p32(cfg.rnn_size))
+    # LSTM bias = b_ih + b_hh, in packed gate order
+    b = (sd["_rnn.bias_ih_l0"] + sd["_rnn.bias_hh_l0"]).numpy()
+    got = pk["lstm"][0]["ih"]["bias"].numpy()[:len(rows)]
+    np.testing.assert_allclose(got[rows >= 0], b[rows[rows >= 0]], rtol=0, atol=0)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/cube_hip.h is exported by the built library and bound
+    by cube_amd.hip (build first: python -c 'import __graft_entry__ as g; g.build()')."""
+    header = open(os.path.join(ROOT, "include", "cube_hip.h")).read()
+    declared = set(re.findall(r"\b(cube_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if d not in ("cube_gemm_args",)}
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.cube_abi_version.restype = ctypes.c_int
+    assert lib.cube_abi_version() == 1
+
+
+def test_parser_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cube_amd.networks.parser import Parser
+    cfg, enc, sd = cases.parser_model(cases.TINY)
+    p = Parser(cfg, enc, ext_word_emb=list(cases.TINY["ext"]))
+    p.load_state_dict(sd)
+    p.to("cpu")
+    doc = cases.document(cases.TINY, enc, "single")
+    with pytest.raises(hip.CubeHipError):
+        p.process(doc, MorphoCollate(enc), batch_size=4)
