@@ -1,0 +1,168 @@
+"""Benchmark of the parser+tagger inference hot path (BASELINE.json metric: sentences/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2]
+
+One "step" = one pass of the hot path over one batch of synthetic sentences whose collated
+inputs are already resident in HBM: device index arrays + external embeddings ->
+heads / labels / UPOS / XPOS / ATTRS ids on the host (one D->H copy).  Config 1 (default,
+BASELINE.json configs[1]): B=256 sentences x L=32 tokens, default ParserConfig, SURVEY.md §8d
+vocabulary, random-init weights (seed 1234).  Config 2: B=64 x L=128.
+
+For N>1 launch with torch.distributed.run (one rank per GPU); ranks shard the sentences (every
+rank processes its own B-sentence batches: weak scaling, no collective on the data path); the
+timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the gated Conv1d GEMM of the
+character CNN, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle,
+i.e. the CPU restatement of the reference path, timed on a bounded sample on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "nlp-cube_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {1: dict(B=256, L=32, name="en parser+tagger B=256 x L=32 (BASELINE configs[1])"),
+           2: dict(B=64, L=128, name="long sentences B=64 x L=128 (BASELINE configs[2])")}
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def build_model_and_batches(cfg_id, n_batches, rank, device, precision):
+    from cube_amd import synth
+    from cube_amd.io_utils.config import ParserConfig
+    from cube_amd.networks.parser import Parser
+    from cube_amd.networks.utils import MorphoCollate
+    c = CONFIGS[cfg_id]
+    cfg = ParserConfig()
+    enc = synth.make_encodings()
+    sd = synth.make_parser_state_dict(cfg, enc, [300], seed=1234)
+    p = Parser(cfg, enc, language_codes=synth.EN_LANGUAGE_CODES, ext_word_emb=[300])
+    if precision:
+        p.precision = precision
+    p.load_state_dict(sd)
+    p.to(device)
+    col = MorphoCollate(enc)
+    batches, docs = [], []
+    for i in range(n_batches):
+        doc = synth.make_document(enc, [c["L"]] * c["B"], seed=1000 * (rank + 1) + i, ext_word_emb=(300,))
+        X = col.collate_fn(doc.sentences)
+        X.pop("y_upos")
+        batches.append(p._prepare(X))
+        docs.append(doc)
+    return p, cfg, enc, sd, batches, docs
+
+
+def hot_path_step(p, bt):
+    """device-resident batch -> five int32 arrays on the host."""
+    r = p.decode_batch_prepared(bt)
+    res = torch.stack([r["heads"], r["labels"], r["upos"].contiguous(), r["xpos"].contiguous(),
+                       r["attrs"].contiguous()])
+    return res.cpu(), r["status"]
+
+
+def cpu_baseline(cfg, enc, sd, doc, n_sent, batch_size):
+    """The oracle (CPU restatement of the reference path, fp32) on a bounded sample."""
+    from oracle import parser_oracle
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    net = parser_oracle.OracleParser(cfg, enc, sd, [300], quant="fp32")
+    sents = doc.sentences[:n_sent]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for s in range(0, len(sents), batch_size):
+            net.decode_batch(parser_oracle.collate(sents[s:s + batch_size], enc))
+    dt = time.perf_counter() - t0
+    return dict(value=len(sents) / dt, unit="sentences/s", cores=threads, kind="port",
+                sample="%d sentences x %d tokens, batch_size %d, oracle fp32 (PyTorch-CPU + NumPy CLE), %.1f s"
+                       % (len(sents), len(sents[0].words), batch_size, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--precision", default="")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+
+    c = CONFIGS[args.config]
+    n_batches = 4
+    p, cfg, enc, sd, batches, docs = build_model_and_batches(args.config, n_batches, rank, device, args.precision)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        hot_path_step(p, batches[i % n_batches])
+    barrier()
+    p.start_kernel_timing("char_conv")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        hot_path_step(p, batches[i % n_batches])
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = p.stop_kernel_timing()
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if dist:
+            td.destroy_process_group()
+        return
+
+    sent_per_s = args.steps * c["B"] * world / dt
+    # ---- roofline of the dominant kernel: char-CNN gated conv GEMM, layers >= 1
+    bt = batches[0]
+    NW = bt["N"] * bt["W"]
+    lay = p._lay
+    kc, nf = lay.char_half + lay.lang, cfg.char_filter_size
+    flops_per_launch = 2.0 * NW * 5 * kc * nf  # algorithmic: 2 * rows * taps * C_in * C_out (SURVEY §8d F_char)
+    ms = kt["ms_mean"]
+    achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms else 0.0
+    roofline = dict(bound="mfma", achieved=achieved, peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / BF16_DENSE_PEAK_TFLOPS, traffic=None, kernel="gemm_kernel<GATE> (char conv, layers>=1)",
+                    launches=kt["n"], ms_per_launch=ms, flops_per_launch=flops_per_launch, padded_W=bt["W"])
+    out = {
+        "metric": "sentences/sec (node) parser+tagger inference", "value": sent_per_s, "unit": "sentences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": p.precision,
+        "data": "synthetic (SURVEY.md 8d: random-init weights seed 1234, synthetic vocabulary and sentences)",
+        "config": {"workload": c["name"], "B": c["B"], "L": c["L"], "padded_W": bt["W"], "ext_emb": [300],
+                   "sharding": "sentences sharded across ranks, no collective on the data path"},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        n = 32 if args.config == 1 else 8
+        out["cpu_baseline"] = cpu_baseline(cfg, enc, sd, docs[0], n, n)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

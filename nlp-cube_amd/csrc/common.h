@@ -28,6 +28,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float x) {  // round-to-nearest-
   bf16_t h = (bf16_t)x;
   return __builtin_bit_cast(uint16_t, h);
 }
+// split an fp32 value into two bf16 terms: v ~= hi + lo with ~16 significant bits ("bf16x2")
+__device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f32_to_bf16(v);
+  lo = f32_to_bf16(v - bf16_to_f32(hi));
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error < 2e-7

@@ -53,6 +53,8 @@ class Parser:
         self._lay = None
         self._buf = None
         self.training = False
+        self.precision = "bf16"
+        self._timing = None
 
     # ---- reference-compatible module surface ----------------------------------------------
     def eval(self):
@@ -92,6 +94,34 @@ class Parser:
         if self._pk is None or self._device.type != "cuda":
             raise hip.CubeHipError("cube_amd Parser runs only on an MI355X: load weights and call .to('cuda:N') "
                                    "(there is no CPU fallback)")
+
+    # ---- live kernel timing (bench.py roofline): HIP events on the launch stream ----------
+    def start_kernel_timing(self, tag):
+        self._timing = dict(tag=tag, pairs=[])
+
+    def stop_kernel_timing(self):
+        t, self._timing = self._timing, None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in t["pairs"]]
+        return dict(tag=t["tag"], n=len(ms), ms_mean=float(np.mean(ms)) if ms else 0.0,
+                    ms_min=float(np.min(ms)) if ms else 0.0)
+
+    def _timed(self, tag):
+        parser = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.on = parser._timing is not None and parser._timing["tag"] == tag
+                if self_.on:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.b = torch.cuda.Event(enable_timing=True)
+                    self_.a.record()
+
+            def __exit__(self_, *exc):
+                if self_.on:
+                    self_.b.record()
+                    parser._timing["pairs"].append((self_.a, self_.b))
+        return _Ctx()
 
     # ---- batch preparation -----------------------------------------------------------------
     def _prepare(self, X):
@@ -166,9 +196,10 @@ class Parser:
         for l, cv in enumerate(pk["char_convs"]):
             last = l == nchar - 1
             dst = None if last else (xca if l % 2 == 0 else xcb)
-            hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xc_w,
-                     col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], res=resc, ld_res=ch,
-                     res_mode=(0 if l == 0 else (2 if last else 1)) if nchar > 1 else 0, stream=st)
+            with self._timed("char_conv" if l > 0 else "char_conv0"):
+                hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst,
+                         ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], res=resc, ld_res=ch,
+                         res_mode=(0 if l == 0 else (2 if last else 1)) if nchar > 1 else 0, stream=st)
             src, src_ld = dst, lay.xc_w
         if nchar == 1:
             # single layer: x + res = 2 g; fold by a second accumulation pass is not needed: res_mode 0 wrote g
@@ -342,7 +373,9 @@ class Parser:
 
     def decode_batch(self, X):
         """One batch of `process` on the device: everything up to the five int32 result arrays."""
-        bt = self._prepare(X)
+        return self.decode_batch_prepared(self._prepare(X))
+
+    def decode_batch_prepared(self, bt):
         r = self._encode(bt)
         heads, status = self._decoder.decode_device(r["arc_probs"], bt["lens"])
         label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], heads)
