@@ -51,21 +51,27 @@ enum {
   CUBE_EPI_BF16_RELU = 3,  /* out0 bf16 = relu(C)                                                */
   CUBE_EPI_GATE = 4        /* gated conv layer, see below                                        */
 };
-/* CUBE_EPI_GATE: N = 2*half output channels packed so that column
+/* Precision.  Every bf16 tensor may come as a pair of planes, x ~= hi + lo ("*_lo" pointers,
+ * same shape and leading dimension as the hi plane).  With A_lo and W_lo given ("bf16x3")
+ * each product is hi*hi + hi*lo + lo*hi on the matrix cores: fp32-grade results, 3 MFMA
+ * passes.  With both NULL ("bf16") one pass.  bf16 outputs are written as hi (and, when the
+ * matching *_lo pointer is given, lo = bf16(v - hi)).
+ *
+ * CUBE_EPI_GATE: N = 2*half output channels packed so that column
  *   n = nb*128 + wc*64 + part*32 + j  holds channel (part ? half : 0) + nb*64 + wc*32 + j;
  * g = tanh(C_a) * sigmoid(C_b) per channel ch.  Then
  *   res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g (and nothing else)
  *   out0 (bf16, optional): [row, col0+ch] = g
  *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference) */
 typedef struct cube_gemm_args {
-  const void* A; int lda; int M; int seq_len; int taps; int Kc;
-  const void* W; int N; const float* bias;
+  const void* A; const void* A_lo; int lda; int M; int seq_len; int taps; int Kc;
+  const void* W; const void* W_lo; int N; const float* bias;
   int epilogue; int n_valid; int accumulate;
-  void* out0; int ldo0; int col0;
+  void* out0; void* out0_lo; int ldo0; int col0;
   const int32_t* rowmap;     /* optional: output row = rowmap[r]; negative = drop the row */
   float* res; int ld_res; int res_mode;
-  void* out1; int ldo1; int col1;
-  void* out2; int ldo2; int col2;
+  void* out1; void* out1_lo; int ldo1; int col1;
+  void* out2; void* out2_lo; int ldo2; int col2;
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 
@@ -75,12 +81,13 @@ int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* tab
 
 /* out[n, c] = bf16( sum_{p < len[n]} x[n*W + p, c] / max(len[n], 1) ),  x f32 [N*W, ld_x], c < C */
 int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C,
-                     void* out, int ld_out, void* stream);
+                     void* out, void* out_lo, int ld_out, void* stream);
 
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
  * bf16(e) -> dst_a[(b*(L+1) + i + 1), col_a..+P) and dst_b[same row, col_b..+P)            */
 int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K,
-                    void* dst_a, int ld_a, int col_a, void* dst_b, int ld_b, int col_b, void* stream);
+                    void* dst_a, void* dst_a_lo, int ld_a, int col_a,
+                    void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream);
 
 /* out[r] = first index of the maximum of x[r, col0 .. col0+n)   (x f32 [M, ld])             */
 int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream);
@@ -90,14 +97,14 @@ int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* ou
  *   packed as dir*G + u*64 + gate*16 + j for hidden unit u*16+j (gate order i,f,g,o).
  * whh bf16 [2][G][KH] (KH = 32*ceil(H/32)): recurrent weights, row = packed gate column.
  * out bf16 [B*T, ld_out]: h_fwd -> cols [col0, col0+H), h_bwd -> [col0+H, col0+2H).        */
-int cube_bilstm_recurrent(const float* gx, const void* whh, int B, int T, int H,
-                          void* out, int ld_out, int col0, void* stream);
+int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, int B, int T, int H,
+                          void* out, void* out_lo, int ld_out, int col0, void* stream);
 
 /* Arc scores + row softmax.  u bf16 [B*T, ld_u] (= [h1;1] W), h2 bf16 [B*T, ld_h2] (cols
  * col_h2..col_h2+D), D % 32 == 0.  logits/probs f32 [B, T-1, T]: [b,i,j] = u[b,i+1,:].h2[b,j,:],
  * probs = softmax over all T columns (pads included, as the reference does).                */
-int cube_biaffine_arc(const void* u, int ld_u, const void* h2, int ld_h2, int col_h2, int D,
-                      int B, int T, float* logits, float* probs, void* stream);
+int cube_biaffine_arc(const void* u, const void* u_lo, int ld_u, const void* h2, const void* h2_lo, int ld_h2,
+                      int col_h2, int D, int B, int T, float* logits, float* probs, void* stream);
 
 /* Chu-Liu-Edmonds single-root decoding.  probs f32 [B, L, L+1], lens int32 [B] ->
  * heads int32 [B, L] (0 at pads), status int32 [B] (0 ok, 1 = no tree: the reference asserts).
@@ -111,7 +118,8 @@ int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L,
  * wl bf16 [n_labels][D][D] ([o][q][p] = W[o,p,q]); bias f32 [n_labels];
  * logits f32 [B, L, n_labels]: [b,i,o] = x1[b,i+1]^T W[o] x2[b, head] + bias[o], head =
  * heads[b,i] if i < lens[b] else 0.  labels int32 [B, L] = argmax_o.                        */
-int cube_label_score(const void* hl, int ld_hl, int col_x2, int D, const void* wl, const float* bias,
+int cube_label_score(const void* hl, const void* hl_lo, int ld_hl, int col_x2, int D,
+                     const void* wl, const void* wl_lo, const float* bias,
                      int n_labels, const int32_t* heads, const int32_t* lens, int B, int L,
                      float* logits, int32_t* labels, void* stream);
 

@@ -21,9 +21,11 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __restrict__ u, int ld_u,
-                                                          const uint16_t* __restrict__ h2, int ld_h2, int col_h2, int D,
-                                                          int B, int T, float* logits, float* probs) {
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ u_lo,
+                                                          int ld_u, const uint16_t* __restrict__ h2,
+                                                          const uint16_t* __restrict__ h2_lo, int ld_h2, int col_h2,
+                                                          int D, int B, int T, float* logits, float* probs) {
   const int L = T - 1;
   const int b = blockIdx.y;
   const int i0 = blockIdx.x * 32;
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __rest
   const int l31 = lane & 31, lh = lane >> 5;
   const int ntile = (T + 31) >> 5;
   const int ia = min(i0 + l31, L - 1);  // clamp: rows beyond L are computed on a valid row and dropped
-  const uint16_t* ap = u + ((size_t)b * T + 1 + ia) * ld_u + lh * 8;
+  const size_t aoff = ((size_t)b * T + 1 + ia) * ld_u + lh * 8;
+  const uint16_t* ap = u + aoff;
   float rmax[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) rmax[r] = -INFINITY;
@@ -40,13 +43,20 @@ __global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __rest
   for (int jt = 0; jt < ntile; ++jt) {
     const int j = jt * 32 + l31;
     const int jb = min(j, T - 1);
-    const uint16_t* bp = h2 + ((size_t)b * T + jb) * ld_h2 + col_h2 + lh * 8;
+    const size_t boff = ((size_t)b * T + jb) * ld_h2 + col_h2 + lh * 8;
+    const uint16_t* bp = h2 + boff;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int k = 0; k < D; k += 16) {
       const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ap + k);
       const bf16x8 fb = *reinterpret_cast<const bf16x8*>(bp + k);
+      if constexpr (SPLIT) {
+        const bf16x8 fal = *reinterpret_cast<const bf16x8*>(u_lo + aoff + k);
+        const bf16x8 fbl = *reinterpret_cast<const bf16x8*>(h2_lo + boff + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbl, acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
     }
 #pragma unroll
@@ -91,16 +101,25 @@ __global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __rest
 
 }  // namespace
 
-extern "C" int cube_biaffine_arc(const void* u, int ld_u, const void* h2, int ld_h2, int col_h2, int D, int B, int T,
-                                 float* logits, float* probs, void* stream) {
+extern "C" int cube_biaffine_arc(const void* u, const void* u_lo, int ld_u, const void* h2, const void* h2_lo,
+                                 int ld_h2, int col_h2, int D, int B, int T, float* logits, float* probs,
+                                 void* stream) {
   if (B <= 0 || T <= 1) return CUBE_OK;
   if (!u || !h2 || !logits || !probs) CUBE_FAIL(CUBE_ERR_ARG, "cube_biaffine_arc: null pointer");
   if (D <= 0 || D % 16 || D > ld_u || col_h2 < 0 || col_h2 + D > ld_h2) CUBE_FAIL(CUBE_ERR_ARG, "cube_biaffine_arc: bad D/columns");
-  if (ld_u % 8 || ld_h2 % 8 || col_h2 % 8 || (uintptr_t)u % 16 || (uintptr_t)h2 % 16)
+  if ((u_lo == nullptr) != (h2_lo == nullptr)) CUBE_FAIL(CUBE_ERR_ARG, "cube_biaffine_arc: u_lo and h2_lo go together");
+  if (ld_u % 8 || ld_h2 % 8 || col_h2 % 8 || (uintptr_t)u % 16 || (uintptr_t)h2 % 16 || (uintptr_t)u_lo % 16 ||
+      (uintptr_t)h2_lo % 16)
     CUBE_FAIL(CUBE_ERR_ALIGN, "cube_biaffine_arc: operands must be 16-byte aligned");
   dim3 grid((T - 1 + 31) / 32, B), block(64);
-  hipLaunchKernelGGL(biaffine_arc_kernel, grid, block, 0, (hipStream_t)stream, (const uint16_t*)u, ld_u,
-                     (const uint16_t*)h2, ld_h2, col_h2, D, B, T, logits, probs);
+  if (u_lo)
+    hipLaunchKernelGGL(biaffine_arc_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)u,
+                       (const uint16_t*)u_lo, ld_u, (const uint16_t*)h2, (const uint16_t*)h2_lo, ld_h2, col_h2, D, B, T,
+                       logits, probs);
+  else
+    hipLaunchKernelGGL(biaffine_arc_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)u,
+                       (const uint16_t*)nullptr, ld_u, (const uint16_t*)h2, (const uint16_t*)nullptr, ld_h2, col_h2, D,
+                       B, T, logits, probs);
   CUBE_CHECK_LAUNCH("cube_biaffine_arc");
   return CUBE_OK;
 }

@@ -8,6 +8,7 @@
 // double-buffered bf16 LDS image that is the A operand of the next step's MFMAs
 // (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  The input projections (all timesteps at once)
 // come from cube_gemm_bf16 and are prefetched one step ahead.
+// SPLIT ("bf16x3"): h and W_hh are hi/lo bf16 pairs, each product is hi*hi + hi*lo + lo*hi.
 #include "common.h"
 #include "../../include/cube_hip.h"
 
@@ -15,9 +16,10 @@ namespace {
 
 constexpr int ROWS = 16;  // sentences per workgroup (= MFMA M)
 
-template <int KSTEPS>
-__global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __restrict__ whh, int B, int T, int H,
-                              uint16_t* __restrict__ out, int ld_out, int col0) {
+template <int KSTEPS, bool SPLIT>
+__global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __restrict__ whh,
+                              const uint16_t* __restrict__ whh_lo, int B, int T, int H, uint16_t* __restrict__ out,
+                              uint16_t* __restrict__ out_lo, int ld_out, int col0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int KH = KSTEPS * 32;
   constexpr int HROW = KH * 2 + 16;  // bytes per h row (padded: conflict-free ds_read_b128)
@@ -29,11 +31,15 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
   const int u = threadIdx.x >> 6;  // hidden-unit group of this wave
   const int l15 = lane & 15, lq = lane >> 4;
 
-  // zero both h images (h_{-1} = 0, K padding = 0)
-  for (int i = threadIdx.x * 4; i < 2 * ROWS * HROW; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(smem + i) = 0u;
+  constexpr int HIMG = ROWS * HROW;            // one h image (one plane of one time step)
+  constexpr int NP = SPLIT ? 2 : 1;
+  // zero all h images (h_{-1} = 0, K padding = 0); layout [step parity][plane][row][k]
+  for (int i = threadIdx.x * 4; i < 2 * NP * HIMG; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(smem + i) = 0u;
   __syncthreads();
 
-  const uint16_t* wbase = whh + ((size_t)dir * G + (size_t)u * 64 + l15) * KH + lq * 8;
+  const size_t woff = ((size_t)dir * G + (size_t)u * 64 + l15) * KH + lq * 8;
+  const uint16_t* wbase = whh + woff;
+  const uint16_t* wbase_lo = SPLIT ? whh_lo + woff : nullptr;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   const int hid = u * 16 + l15;
   const size_t gx_ld = (size_t)2 * G;
@@ -64,22 +70,31 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
     for (int g = 0; g < 4; ++g) acc[g] = nxt[g];
     if (s + 1 < T) load_gx(dir ? t - 1 : t + 1);
 
-    const unsigned char* hb = smem + cur * ROWS * HROW + l15 * HROW + lq * 16;
+    const unsigned char* hb = smem + cur * NP * HIMG + l15 * HROW + lq * 16;
     // W_hh is re-streamed from L2 every step: 7 k-steps x 4 gates of B fragments are 112 VGPRs per
     // wave, more than the 128-register budget of a 13-wave workgroup leaves.  Laundering the
     // pointer keeps hipcc from hoisting (and then spilling) the loads out of the time loop.
     const uint16_t* wb = wbase;
+    const uint16_t* wl = wbase_lo;
     asm volatile("" : "+v"(wb));
+    if constexpr (SPLIT) asm volatile("" : "+v"(wl));
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(hb + ks * 64);
+      bf16x8 al;
+      if constexpr (SPLIT) al = *reinterpret_cast<const bf16x8*>(hb + HIMG + ks * 64);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + (size_t)g * 16 * KH + ks * 32);
+        if constexpr (SPLIT) {
+          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + (size_t)g * 16 * KH + ks * 32);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w2, acc[g], 0, 0, 0);
+        }
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc[g], 0, 0, 0);
       }
     }
-    unsigned char* hn = smem + (cur ^ 1) * ROWS * HROW;
+    unsigned char* hn = smem + (cur ^ 1) * NP * HIMG;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ig = sigmoidf_(acc[0][r]);
@@ -87,11 +102,18 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
       const float gg = tanhf_(acc[2][r]);
       const float og = sigmoidf_(acc[3][r]);
       c[r] = fg * c[r] + ig * gg;
-      const uint16_t hv = f32_to_bf16(og * tanhf_(c[r]));
+      const float hf = og * tanhf_(c[r]);
+      uint16_t hv, hl = 0;
+      if constexpr (SPLIT) split_bf16(hf, hv, hl); else hv = f32_to_bf16(hf);
       const int row = lq * 4 + r;
       *reinterpret_cast<uint16_t*>(hn + row * HROW + hid * 2) = hv;
+      if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(hn + HIMG + row * HROW + hid * 2) = hl;
       const int b = b0 + row;
-      if (b < B && hid < H) out[((size_t)b * T + t) * ld_out + col0 + dir * H + hid] = hv;
+      if (b < B && hid < H) {
+        const size_t o = ((size_t)b * T + t) * ld_out + col0 + dir * H + hid;
+        out[o] = hv;
+        if constexpr (SPLIT) out_lo[o] = hl;
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -100,23 +122,30 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
 
 }  // namespace
 
-extern "C" int cube_bilstm_recurrent(const float* gx, const void* whh, int B, int T, int H, void* out, int ld_out,
-                                     int col0, void* stream) {
+extern "C" int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, int B, int T, int H,
+                                     void* out, void* out_lo, int ld_out, int col0, void* stream) {
   if (B <= 0 || T <= 0) return CUBE_OK;
   if (!gx || !whh || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: null pointer");
   if (H <= 0 || H > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: rnn_size=%d unsupported (1..256)", H);
   if (col0 < 0 || col0 + 2 * H > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: bad output columns");
-  if ((uintptr_t)whh % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_bilstm_recurrent: whh must be 16-byte aligned");
+  if ((whh_lo == nullptr) != (out_lo == nullptr))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: whh_lo and out_lo must be given together (bf16x3) or not at all");
+  if ((uintptr_t)whh % 16 || (uintptr_t)whh_lo % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_bilstm_recurrent: whh must be 16-byte aligned");
   const int U = (H + 15) / 16;
   const int ksteps = (H + 31) / 32;
   const int KH = ksteps * 32;
-  const size_t lds = (size_t)2 * ROWS * (KH * 2 + 16);
+  const bool split = whh_lo != nullptr;
+  const size_t lds = (size_t)2 * (split ? 2 : 1) * ROWS * (KH * 2 + 16);
   dim3 grid((B + ROWS - 1) / ROWS, 2), block(64 * U);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(KS)                                                                                                  \
-  case KS:                                                                                                          \
-    hipLaunchKernelGGL(bilstm_kernel<KS>, grid, block, lds, st, gx, (const uint16_t*)whh, B, T, H, (uint16_t*)out, \
-                       ld_out, col0);                                                                               \
+#define LAUNCH(KS)                                                                                               \
+  case KS:                                                                                                       \
+    if (split)                                                                                                   \
+      hipLaunchKernelGGL((bilstm_kernel<KS, true>), grid, block, lds, st, gx, (const uint16_t*)whh,              \
+                         (const uint16_t*)whh_lo, B, T, H, (uint16_t*)out, (uint16_t*)out_lo, ld_out, col0);     \
+    else                                                                                                         \
+      hipLaunchKernelGGL((bilstm_kernel<KS, false>), grid, block, lds, st, gx, (const uint16_t*)whh,             \
+                         (const uint16_t*)nullptr, B, T, H, (uint16_t*)out, (uint16_t*)nullptr, ld_out, col0);   \
     break;
   switch (ksteps) {
     LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)

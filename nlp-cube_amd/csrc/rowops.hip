@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, int ld_
 
 // ---- masked mean over the W character positions of each word
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float* x, int ld_x, const int32_t* len, int N, int W,
-                                                          int C, uint16_t* out, int ld_out) {
+                                                          int C, uint16_t* out, uint16_t* out_lo, int ld_out) {
   const int n = blockIdx.x;
   if (n >= N) return;
   const int l = min(max(len[n], 0), W);
@@ -53,21 +53,33 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* x, int ld
     float s = 0.f;
     const float* p = x + (size_t)n * W * ld_x + c;
     for (int q = 0; q < l; ++q) s += p[(size_t)q * ld_x];
-    out[(size_t)n * ld_out + c] = f32_to_bf16(s / den);
+    const float v = s / den;
+    if (out_lo) {
+      uint16_t h, lo;
+      split_bf16(v, h, lo);
+      out[(size_t)n * ld_out + c] = h;
+      out_lo[(size_t)n * ld_out + c] = lo;
+    } else {
+      out[(size_t)n * ld_out + c] = f32_to_bf16(v);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int P, float K,
-                                                         uint16_t* da, int ld_a, int col_a, uint16_t* db, int ld_b,
-                                                         int col_b) {
+                                                         uint16_t* da, uint16_t* da_lo, int ld_a, int col_a,
+                                                         uint16_t* db, uint16_t* db_lo, int ld_b, int col_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * L * P) return;
   const int r = t / P, c = t - r * P;
   const int b = r / L, i = r - b * L;
-  const uint16_t v = f32_to_bf16(tanhf_(acc[(size_t)r * ld_acc + c] / K));
+  const float e = tanhf_(acc[(size_t)r * ld_acc + c] / K);
+  uint16_t v, vl;
+  split_bf16(e, v, vl);
   const size_t orow = (size_t)b * (L + 1) + i + 1;
   if (da) da[orow * ld_a + col_a + c] = v;
   if (db) db[orow * ld_b + col_b + c] = v;
+  if (da_lo) da_lo[orow * ld_a + col_a + c] = vl;
+  if (db_lo) db_lo[orow * ld_b + col_b + c] = vl;
 }
 
 // ---- arg-max (first maximal index, like torch.argmax / numpy.argmax): one wave per row
@@ -113,23 +125,24 @@ extern "C" int cube_gather_rows(void* dst, int ld_dst, int col0, int width, cons
 }
 
 extern "C" int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C, void* out,
-                                int ld_out, void* stream) {
+                                void* out_lo, int ld_out, void* stream) {
   if (N <= 0) return CUBE_OK;
   if (!x || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
   hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ld_x, len, N, W, C,
-                     (uint16_t*)out, ld_out);
+                     (uint16_t*)out, (uint16_t*)out_lo, ld_out);
   CUBE_CHECK_LAUNCH("cube_masked_mean");
   return CUBE_OK;
 }
 
-extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K, void* dst_a, int ld_a,
-                               int col_a, void* dst_b, int ld_b, int col_b, void* stream) {
+extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K, void* dst_a, void* dst_a_lo,
+                               int ld_a, int col_a, void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream) {
   if (B <= 0 || L <= 0 || P <= 0) return CUBE_OK;
   if (!acc || K <= 0 || P > ld_acc) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
   if ((dst_a && col_a + P > ld_a) || (dst_b && col_b + P > ld_b)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad columns");
   const int total = B * L * P;
   hipLaunchKernelGGL(ext_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, ld_acc, B, L,
-                     P, (float)K, (uint16_t*)dst_a, ld_a, col_a, (uint16_t*)dst_b, ld_b, col_b);
+                     P, (float)K, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
+                     (uint16_t*)dst_b_lo, ld_b, col_b);
   CUBE_CHECK_LAUNCH("cube_ext_finish");
   return CUBE_OK;
 }

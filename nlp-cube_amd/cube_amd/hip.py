@@ -16,15 +16,39 @@ c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
 class GemmArgs(ctypes.Structure):
     _fields_ = [
-        ("A", c_void_p), ("lda", c_int), ("M", c_int), ("seq_len", c_int), ("taps", c_int), ("Kc", c_int),
-        ("W", c_void_p), ("N", c_int), ("bias", c_void_p),
+        ("A", c_void_p), ("A_lo", c_void_p), ("lda", c_int), ("M", c_int), ("seq_len", c_int), ("taps", c_int),
+        ("Kc", c_int),
+        ("W", c_void_p), ("W_lo", c_void_p), ("N", c_int), ("bias", c_void_p),
         ("epilogue", c_int), ("n_valid", c_int), ("accumulate", c_int),
-        ("out0", c_void_p), ("ldo0", c_int), ("col0", c_int),
+        ("out0", c_void_p), ("out0_lo", c_void_p), ("ldo0", c_int), ("col0", c_int),
         ("rowmap", c_void_p),
         ("res", c_void_p), ("ld_res", c_int), ("res_mode", c_int),
-        ("out1", c_void_p), ("ldo1", c_int), ("col1", c_int),
-        ("out2", c_void_p), ("ldo2", c_int), ("col2", c_int),
+        ("out1", c_void_p), ("out1_lo", c_void_p), ("ldo1", c_int), ("col1", c_int),
+        ("out2", c_void_p), ("out2_lo", c_void_p), ("ldo2", c_int), ("col2", c_int),
     ]
+
+
+class Pair:
+    """A bf16 tensor as hi (+ optional lo) planes: x ~= hi + lo."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def split(x, with_lo=True):
+        """fp32 tensor -> Pair of bf16 planes (host or device)."""
+        import torch
+        hi = x.to(torch.bfloat16)
+        lo = (x.to(torch.float32) - hi.to(torch.float32)).to(torch.bfloat16) if with_lo else None
+        return Pair(hi, lo)
+
+    def float(self):
+        f = self.hi.float()
+        return f if self.lo is None else f + self.lo.float()
+
+    def to(self, device):
+        return Pair(self.hi.to(device), None if self.lo is None else self.lo.to(device))
 
 
 # name -> (restype, argtypes); every symbol declared in include/cube_hip.h
@@ -33,17 +57,18 @@ SIGNATURES = {
     "cube_abi_version": (c_int, []),
     "cube_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "cube_gather_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "cube_masked_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                c_int, c_void_p]),
+    "cube_masked_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "cube_bilstm_recurrent": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "cube_biaffine_arc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                  c_void_p]),
+    "cube_bilstm_recurrent": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                      c_int, c_void_p]),
+    "cube_biaffine_arc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
     "cube_mst_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cube_mst_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "cube_label_score": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                 c_int, c_void_p, c_void_p, c_void_p]),
+    "cube_label_score": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                 c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -85,19 +110,37 @@ def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _planes(x, col=0):
+    """(hi pointer, lo pointer) of a Pair / tensor / None, advanced by `col` bf16 elements."""
+    if x is None:
+        return None, None
+    if isinstance(x, Pair):
+        return x.hi.data_ptr() + 2 * col, (None if x.lo is None else x.lo.data_ptr() + 2 * col)
+    return x.data_ptr() + 2 * col, None
+
+
 def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
          rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
          a_col=0, stream=None):
-    """A/out*: torch tensors (device) or raw int pointers; a_col: starting column of A (bf16 elements)."""
+    """A, W, out0 (bf16 epilogues), out1, out2: `Pair`s; out0 of CUBE_EPI_F32: an fp32 tensor.
+    bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements)."""
     a = GemmArgs()
-    a_ptr = A if isinstance(A, int) else A.data_ptr()
-    a.A = a_ptr + 2 * a_col
+    a.A, a.A_lo = _planes(A, a_col)
+    a.W, a.W_lo = _planes(W)
+    if a.A_lo is None or a.W_lo is None:
+        a.A_lo = a.W_lo = None
     a.lda, a.M, a.seq_len, a.taps, a.Kc = lda, M, seq_len, taps, Kc
-    a.W, a.N, a.bias = ptr(W), N, ptr(bias)
+    a.N, a.bias = N, ptr(bias)
     a.epilogue, a.n_valid, a.accumulate = epilogue, n_valid, accumulate
-    a.out0, a.ldo0, a.col0 = ptr(out0), ldo0, col0
+    if epilogue == EPI_F32:
+        a.out0, a.out0_lo = ptr(out0), None
+    else:
+        a.out0, a.out0_lo = _planes(out0)
+    a.ldo0, a.col0 = ldo0, col0
     a.rowmap = ptr(rowmap)
     a.res, a.ld_res, a.res_mode = ptr(res), ld_res, res_mode
-    a.out1, a.ldo1, a.col1 = ptr(out1), ldo1, col1
-    a.out2, a.ldo2, a.col2 = ptr(out2), ldo2, col2
+    a.out1, a.out1_lo = _planes(out1)
+    a.ldo1, a.col1 = ldo1, col1
+    a.out2, a.out2_lo = _planes(out2)
+    a.ldo2, a.col2 = ldo2, col2
     check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")

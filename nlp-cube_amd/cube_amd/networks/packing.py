@@ -30,7 +30,9 @@ def p128(x):
 
 
 def _bf16(t):
-    return t.to(torch.float32).contiguous().to(torch.bfloat16)
+    """fp32 -> Pair(hi, lo) of bf16 planes, t ~= hi + lo (the lo plane is used by bf16x3 only)."""
+    from cube_amd.hip import Pair
+    return Pair.split(t.to(torch.float32).contiguous())
 
 
 def gate_column_order(half):
@@ -277,11 +279,14 @@ def pack_tagger(sd, cfg, enc_sizes, ext_dims):
     return pk, lay
 
 
-def to_device(obj, device):
+def to_device(obj, device, with_lo=True):
+    from cube_amd.hip import Pair
+    if isinstance(obj, Pair):
+        return Pair(obj.hi.to(device), obj.lo.to(device) if (with_lo and obj.lo is not None) else None)
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
     if isinstance(obj, dict):
-        return {k: to_device(v, device) for k, v in obj.items()}
+        return {k: to_device(v, device, with_lo) for k, v in obj.items()}
     if isinstance(obj, list):
-        return [to_device(v, device) for v in obj]
+        return [to_device(v, device, with_lo) for v in obj]
     return obj

@@ -3,8 +3,13 @@
 Host-side mirror of the reference `Parser` (cube/networks/parser.py:22-95, 109-233,
 400-448): same constructor, `load`, `to`, `forward`, `_get_labels` and `process` signatures
 and results, but every tensor operation of the path runs in hand-written gfx950 kernels
-behind the C ABI of include/cube_hip.h (bf16 MFMA operands, fp32 accumulation; the
-arithmetic contract is restated by oracle/parser_oracle.py, quant="bf16").
+behind the C ABI of include/cube_hip.h.
+
+Precision (`Parser.precision`): "bf16x3" (default) keeps every activation and weight as a
+hi/lo pair of bf16 planes and forms each product as hi*hi + hi*lo + lo*hi on the matrix cores
+with fp32 accumulation — fp32-grade results, checked directly against the reference's own
+outputs (tests/golden) to the north-star tolerance; "bf16" is the single-pass mode (one
+plane, 3x fewer MFMAs) whose arithmetic contract is oracle/parser_oracle.py quant="bf16".
 
 Per batch: 1 upload of int32 indices + bf16 external embeddings, ~45 asynchronous kernel
 launches on the current HIP stream, 1 download of five int32 arrays — the reference's three
@@ -22,17 +27,24 @@ from cube_amd.networks.utils import MorphoCollate, MorphoDataset, ChuLiuEdmondsD
 
 class _Buffers:
     """Grow-only, zero-initialised flat device buffers with fixed leading dimensions, so the
-    padding columns no kernel writes stay zero for the life of the model."""
+    padding columns no kernel writes stay zero for the life of the model.  bf16 buffers are
+    `hip.Pair`s (hi plane + lo plane when the precision is bf16x3)."""
 
-    def __init__(self, device):
+    def __init__(self, device, split):
         self.device = device
+        self.split = split
         self._b = {}
 
     def get(self, name, rows, ld, dtype=torch.bfloat16):
-        need = rows * ld
+        need = max(rows * ld, 1)
         t = self._b.get(name)
-        if t is None or t.numel() < need or t.dtype != dtype:
-            t = torch.zeros(max(need, 1), dtype=dtype, device=self.device)
+        numel = 0 if t is None else (t.hi.numel() if isinstance(t, hip.Pair) else t.numel())
+        if t is None or numel < need:
+            if dtype == torch.bfloat16:
+                t = hip.Pair(torch.zeros(need, dtype=dtype, device=self.device),
+                             torch.zeros(need, dtype=dtype, device=self.device) if self.split else None)
+            else:
+                t = torch.zeros(need, dtype=dtype, device=self.device)
             self._b[name] = t
         return t
 
@@ -53,7 +65,7 @@ class Parser:
         self._lay = None
         self._buf = None
         self.training = False
-        self.precision = "bf16"
+        self.precision = "bf16x3"  # or "bf16"; set before .to(device)
         self._timing = None
 
     # ---- reference-compatible module surface ----------------------------------------------
@@ -86,8 +98,11 @@ class Parser:
         hip.load()
         self._device = device
         if self._pk_cpu is not None:
-            self._pk = packing.to_device(self._pk_cpu, device)
-            self._buf = _Buffers(device)
+            if self.precision not in ("bf16x3", "bf16"):
+                raise ValueError("precision must be 'bf16x3' or 'bf16'")
+            self._split = self.precision == "bf16x3"
+            self._pk = packing.to_device(self._pk_cpu, device, with_lo=self._split)
+            self._buf = _Buffers(device, self._split)
         return self
 
     def _require_gpu(self):
@@ -126,7 +141,8 @@ class Parser:
     # ---- batch preparation -----------------------------------------------------------------
     def _prepare(self, X):
         """reference-format batch dict (MorphoCollate.collate_fn) -> device index arrays.
-        One packed int32 upload + one bf16 upload per LM layer."""
+        One packed int32 upload + one (hi[, lo]) bf16 upload per LM layer."""
+        self._require_gpu()
         dev = self._device
         x_sent = X["x_sent"].cpu().numpy()
         sl = X["x_sent_len"].cpu().numpy().astype(np.int64)
@@ -156,29 +172,42 @@ class Parser:
         embs = []
         for k, e in enumerate(X["x_word_embeddings"]):
             ek = self._pk["ext"][k]
-            pad = torch.zeros((B, L, ek["Epad"]), dtype=torch.bfloat16)
-            pad.view(B * L, -1)[torch.from_numpy(sb * L + si), :ek["E"]] = e.cpu().to(torch.bfloat16)
-            embs.append(pad.to(dev, non_blocking=True))
+            pad = torch.zeros((B * L, ek["Epad"]), dtype=torch.float32)
+            pad[torch.from_numpy(sb * L + si), :ek["E"]] = e.cpu().to(torch.float32)
+            embs.append(hip.Pair.split(pad, with_lo=self._split).to(dev))
         bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs)
         if "y_upos" in X:
             bt["y_upos"] = X["y_upos"].to(dev).to(torch.int32).contiguous()
         return bt
 
     # ---- the device pipeline ---------------------------------------------------------------
+    def _gather(self, dst, ld, col0, width, table, idx, rows, n):
+        """embedding lookup / row copy into a concat buffer, every plane (hi[, lo])."""
+        lib, st = hip.load(), hip.stream_handle()
+        for d, t in ((dst.hi, table.hi), (dst.lo, table.lo)):
+            if d is None or t is None:
+                continue
+            hip.check(lib.cube_gather_rows(d.data_ptr(), ld, col0, width, t.data_ptr(), t.shape[1], hip.ptr(idx),
+                                           hip.ptr(rows), n, st), "cube_gather_rows")
+
+    @staticmethod
+    def _zero(pair, numel):
+        pair.hi[:numel].zero_()
+        if pair.lo is not None:
+            pair.lo[:numel].zero_()
+
     def _encode(self, bt, want_aux=False):
         """Runs char-CNN, ext MLPs, word-CNN, morphology heads, BiLSTM, pre_parsing and the arc
         scorer.  Returns a dict of device tensors (views into the workspace)."""
         self._require_gpu()
         lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
         st = hip.stream_handle()
+        gather = self._gather
+        lo = hip.ptr  # lo-plane pointer helper: hip.ptr(pair.lo) is None in single-pass mode
         B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
         NW, BT, BL = N * W, B * T, B * L
         ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
         H = cfg.rnn_size
-
-        def gather(dst, ld, col0, width, table, idx, rows, n):
-            hip.check(lib.cube_gather_rows(dst.data_ptr(), ld, col0, width, table.data_ptr(), table.shape[1],
-                                           hip.ptr(idx), hip.ptr(rows), n, st), "cube_gather_rows")
 
         # ---- character level (WordGram, modules.py:450-484)
         xc0 = buf.get("xc0", NW, lay.xc0_w)
@@ -202,15 +231,14 @@ class Parser:
                          res_mode=(0 if l == 0 else (2 if last else 1)) if nchar > 1 else 0, stream=st)
             src, src_ld = dst, lay.xc_w
         if nchar == 1:
-            # single layer: x + res = 2 g; fold by a second accumulation pass is not needed: res_mode 0 wrote g
-            resc.mul_(2.0)
+            resc[:NW * ch].mul_(2.0)  # single layer: x + res = 2 g
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
-        hip.check(lib.cube_masked_mean(resc.data_ptr(), ch, bt["word_len"].data_ptr(), N, W, ch, pool.data_ptr(), pool_w,
-                                       st), "cube_masked_mean")
+        hip.check(lib.cube_masked_mean(resc.data_ptr(), ch, bt["word_len"].data_ptr(), N, W, ch, pool.hi.data_ptr(),
+                                       lo(pool.lo), pool_w, st), "cube_masked_mean")
         # ---- word level input XW0 = [word | char | lang | ext], root row = _r_emb
         xw0 = buf.get("xw0", BT, lay.xw0_w)
-        xw0[:BT * lay.xw0_w].zero_()
+        self._zero(xw0, BT * lay.xw0_w)
         gather(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT)
         po = pk["char_pre_out"]
         hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
@@ -219,18 +247,19 @@ class Parser:
         # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138)
         xl0_w = p32(wh + lg + P)
         xl0 = buf.get("xl0", BT, xl0_w)
-        xl0[:BT * xl0_w].zero_()
+        self._zero(xl0, BT * xl0_w)
         ext_h = buf.get("ext_h", BL, pk["ext"][0]["h1"]["N"])
-        ext_acc = buf.get("ext_acc", BL, 8 * ((P + 7) // 8), torch.float32)
         ld_acc = 8 * ((P + 7) // 8)
+        ext_acc = buf.get("ext_acc", BL, ld_acc, torch.float32)
         for k, ek in enumerate(pk["ext"]):
             h1, h2 = ek["h1"], ek["h2"]
             hip.gemm(bt["embs"][k], ek["Epad"], BL, h1["K"], h1["W"], h1["N"], h1["bias"], hip.EPI_BF16_TANH,
                      out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
             hip.gemm(ext_h, h1["N"], BL, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
                      n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
-        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, P, len(pk["ext"]), xw0.data_ptr(), lay.xw0_w,
-                                      lay.xw0_ext, xl0.data_ptr(), xl0_w, wh + lg, st), "cube_ext_finish")
+        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, P, len(pk["ext"]), xw0.hi.data_ptr(),
+                                      lo(xw0.lo), lay.xw0_w, lay.xw0_ext, xl0.hi.data_ptr(), lo(xl0.lo), xl0_w,
+                                      wh + lg, st), "cube_ext_finish")
         gather(xw0, lay.xw0_w, 0, lay.xw0_w, pk["r_emb"], None, bt["root_rows"], B)
         out = {}
         if want_aux:
@@ -244,10 +273,8 @@ class Parser:
         resw = buf.get("resw", BT, wh, torch.float32)
         xm_w = p32(wh + lg)
         xm = buf.get("xm", BT, xm_w)
-        gather(xwa, lay.xw_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        gather(xwb, lay.xw_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        gather(xm, xm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        gather(xl0, xl0_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        for dstb, ldb in ((xwa, lay.xw_w), (xwb, lay.xw_w), (xm, xm_w), (xl0, xl0_w)):
+            gather(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         nword = len(pk["word_convs"])
         src, src_ld = xw0, lay.xw0_w
         for l, cv in enumerate(pk["word_convs"]):
@@ -297,8 +324,8 @@ class Parser:
             dst = xla if l % 2 == 0 else xlb
             hip.gemm(src, src_ld, BT, ih["K"], ih["W"], ih["N"], ih["bias"], hip.EPI_F32, out0=gx, ldo0=G2, n_valid=G2,
                      stream=st)
-            hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].data_ptr(), B, T, H, dst.data_ptr(), xl_w, 0,
-                                                st), "cube_bilstm_recurrent")
+            hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].hi.data_ptr(), lo(ly["whh"].lo), B, T, H,
+                                                dst.hi.data_ptr(), lo(dst.lo), xl_w, 0, st), "cube_bilstm_recurrent")
             src, src_ld = dst, xl_w
         # ---- pre_parsing (parser.py:202-203) and the arc scorer (modules.py:518-533, 550-579)
         q = pk["pre_out"]
@@ -316,8 +343,8 @@ class Parser:
         hip.gemm(ha, 2 * Dh, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
         arc_logits = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
         arc_probs = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
-        hip.check(lib.cube_biaffine_arc(u.data_ptr(), Dh, ha.data_ptr(), 2 * Dh, Dh, Dh, B, T, arc_logits.data_ptr(),
-                                        arc_probs.data_ptr(), st), "cube_biaffine_arc")
+        hip.check(lib.cube_biaffine_arc(u.hi.data_ptr(), lo(u.lo), Dh, ha.hi.data_ptr(), lo(ha.lo), 2 * Dh, Dh, Dh, B, T,
+                                        arc_logits.data_ptr(), arc_probs.data_ptr(), st), "cube_biaffine_arc")
         out.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w,
                    upos_logits=upos_log.view(B, T, n_u)[:, 1:, :], upos_idx=upos_idx.view(B, T)[:, 1:],
                    ax_logits=ax_log.view(B, T, n_ax)[:, 1:, :], ax_all=ax_log)
@@ -337,9 +364,10 @@ class Parser:
         logits = torch.empty((B, L, n_l), dtype=torch.float32, device=self._device)
         labels = torch.empty((B, L), dtype=torch.int32, device=self._device)
         lb = pk["label_bilin"]
-        hip.check(lib.cube_label_score(hl.data_ptr(), 2 * Dl, Dl, Dl, lb["W"].data_ptr(), lb["bias"].data_ptr(), n_l,
-                                       heads_dev.data_ptr(), bt["lens"].data_ptr(), B, L, logits.data_ptr(),
-                                       labels.data_ptr(), st), "cube_label_score")
+        hip.check(lib.cube_label_score(hl.hi.data_ptr(), hip.ptr(hl.lo), 2 * Dl, Dl, Dl, lb["W"].hi.data_ptr(),
+                                       hip.ptr(lb["W"].lo), lb["bias"].data_ptr(), n_l, heads_dev.data_ptr(),
+                                       bt["lens"].data_ptr(), B, L, logits.data_ptr(), labels.data_ptr(), st),
+                  "cube_label_score")
         return logits, labels
 
     # ---- reference API ---------------------------------------------------------------------
@@ -351,7 +379,9 @@ class Parser:
         r = self._encode(bt, want_aux=True)
         B, L, T = bt["B"], bt["L"], bt["T"]
         n_u, n_x, n_a = self._sizes["upos"], self._sizes["xpos"], self._sizes["attrs"]
-        pre = r["pp"][:B * T * r["pp_w"]].view(B, T, r["pp_w"])[:, :, :self._config.pre_parser_size].float()
+        n_pp = B * T * r["pp_w"]
+        pre = hip.Pair(r["pp"].hi[:n_pp], None if r["pp"].lo is None else r["pp"].lo[:n_pp]).float()
+        pre = pre.view(B, T, r["pp_w"])[:, :, :self._config.pre_parser_size]
         attrs, xpos = r["ax_logits"][:, :, :n_a], r["ax_logits"][:, :, n_a:n_a + n_x]
         aux = r["aux"].view(B, T, -1)[:, 1:, :]
         return (r["arc_logits"], pre, r["upos_logits"], xpos, attrs, aux[:, :, :n_u], aux[:, :, n_u:n_u + n_x],
@@ -367,7 +397,10 @@ class Parser:
             hp[b, :len(h)] = np.asarray(h)
         pp_w = self._pk["pre_out"]["N"]
         pp = self._buf.get("pp_ext", B * T, pp_w)
-        pp[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = labels.to(self._device).to(torch.bfloat16)
+        src = hip.Pair.split(labels.to(self._device).to(torch.float32), with_lo=self._split)
+        pp.hi[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = src.hi
+        if self._split:
+            pp.lo[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = src.lo
         logits, _ = self._label_scores(bt, pp, pp_w, torch.from_numpy(hp).to(self._device))
         return logits
 

@@ -35,20 +35,24 @@ def _bf16_round(x):
 # ------------------------------------------------------------------------------------------
 # cube_gemm_bf16
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("M,seq,taps,Kc,N,epi", [
     (300, 300, 1, 64, 128, "f32"), (257, 257, 1, 352, 256, "tanh"), (4 * 33, 33, 5, 96, 128, "relu"),
     (7 * 13, 13, 5, 32, 128, "bf16"), (1000, 1000, 1, 512, 384, "f32"),
 ])
-def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi):
+def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
+    """bf16 (one pass, operands already bf16-exact) and bf16x3 (hi/lo planes of arbitrary fp32
+    operands) against an fp64 matmul of the same operands."""
     from cube_amd import hip
     g = torch.Generator().manual_seed(M + Kc + N)
     lda = Kc + 32
-    A = _bf16_round(torch.randn((M, lda), generator=g))
-    W = _bf16_round(torch.randn((N, taps * Kc), generator=g) / np.sqrt(taps * Kc))
+    A = torch.randn((M, lda), generator=g)
+    W = torch.randn((N, taps * Kc), generator=g) / np.sqrt(taps * Kc)
+    if not split:
+        A, W = _bf16_round(A), _bf16_round(W)
     bias = torch.randn(N, generator=g)
-    # reference: zero-padded taps inside each sequence of `seq` rows
-    Ar = A[:, :Kc].view(M // seq, seq, Kc)
-    ref = torch.zeros((M // seq, seq, N))
+    Ar = A[:, :Kc].double().view(M // seq, seq, Kc)
+    ref = torch.zeros((M // seq, seq, N), dtype=torch.float64)
     for t in range(taps):
         d = t - taps // 2
         sh = torch.zeros_like(Ar)
@@ -58,63 +62,83 @@ def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi):
             sh[:, :seq - d] = Ar[:, d:]
         else:
             sh = Ar
-        ref += sh @ W[:, t * Kc:(t + 1) * Kc].t()
-    ref = ref.view(M, N) + bias
-    n_valid = N - 5
-    Ad, Wd, bd = A.to(torch.bfloat16).to(dev), W.to(torch.bfloat16).to(dev), bias.to(dev)
-    code = dict(f32=hip.EPI_F32, bf16=hip.EPI_BF16, tanh=hip.EPI_BF16_TANH, relu=hip.EPI_BF16_RELU)[epi]
-    ldo = N + 8
-    out = torch.full((M, ldo), 7.0, dtype=torch.float32 if epi == "f32" else torch.bfloat16, device=dev)
-    hip.gemm(Ad, lda, M, Kc, Wd, N, bd, code, out0=out, ldo0=ldo, col0=8, taps=taps, seq_len=seq, n_valid=n_valid)
-    torch.cuda.synchronize()
-    got = out.float().cpu()
+        ref += sh @ W[:, t * Kc:(t + 1) * Kc].double().t()
+    ref = (ref.view(M, N) + bias.double())
     if epi == "tanh":
         ref = torch.tanh(ref)
     if epi == "relu":
         ref = torch.relu(ref)
-    tol = 2e-5 if epi == "f32" else 1e-2
+    ref = ref.float()
+    n_valid = N - 5
+    Ad, Wd, bd = hip.Pair.split(A, split).to(dev), hip.Pair.split(W, split).to(dev), bias.to(dev)
+    code = dict(f32=hip.EPI_F32, bf16=hip.EPI_BF16, tanh=hip.EPI_BF16_TANH, relu=hip.EPI_BF16_RELU)[epi]
+    ldo = N + 8
+    if epi == "f32":
+        out = torch.full((M, ldo), 7.0, dtype=torch.float32, device=dev)
+    else:
+        out = hip.Pair(torch.full((M, ldo), 7.0, dtype=torch.bfloat16, device=dev),
+                       torch.full((M, ldo), 7.0, dtype=torch.bfloat16, device=dev) if split else None)
+    hip.gemm(Ad, lda, M, Kc, Wd, N, bd, code, out0=out, ldo0=ldo, col0=8, taps=taps, seq_len=seq, n_valid=n_valid)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    tol = 3e-5 if (epi == "f32" or split) else 1e-2  # bf16 outputs of one plane carry 2^-9 rounding
     np.testing.assert_allclose(got[:, 8:8 + n_valid].numpy(), ref[:, :n_valid].numpy(), rtol=tol, atol=tol)
-    assert (got[:, :8] == 7.0).all() and (got[:, 8 + n_valid:] == 7.0).all()  # nothing outside the valid columns
+    planes = [out] if epi == "f32" else [out.hi] + ([out.lo] if split else [])
+    for pl in planes:  # nothing outside the valid columns
+        pl = pl.float().cpu()
+        assert (pl[:, :8] == 7.0).all() and (pl[:, 8 + n_valid:] == 7.0).all()
 
 
-def test_gemm_gate_epilogue_and_rowmap(dev):
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_gate_epilogue_and_rowmap(dev, split):
     from cube_amd import hip
     from cube_amd.networks import packing
     g = torch.Generator().manual_seed(5)
     M, seq, Kc, half = 6 * 11, 11, 64, 80
-    A = _bf16_round(torch.randn((M, Kc), generator=g))
+    A = torch.randn((M, Kc), generator=g)
+    if not split:
+        A = _bf16_round(A)
     w = torch.randn((2 * half, Kc, 5), generator=g) / np.sqrt(5 * Kc)
     sd = {"c.0.conv.weight": w, "c.0.conv.bias": torch.randn(2 * half, generator=g) * 0.1,
           "c.1.weight": torch.rand(2 * half, generator=g) + 0.5, "c.1.bias": torch.randn(2 * half, generator=g) * 0.1,
           "c.1.running_mean": torch.randn(2 * half, generator=g) * 0.1, "c.1.running_var": torch.rand(2 * half, generator=g) + 0.5}
     pk = packing.pack_gated_conv(sd, "c", np.arange(Kc))
     s = sd["c.1.weight"] / torch.sqrt(sd["c.1.running_var"] + 1e-5)
-    wf = _bf16_round(w * s[:, None, None])
+    wf = w * s[:, None, None]
+    if not split:
+        wf = _bf16_round(wf)
     bf = (sd["c.0.conv.bias"] - sd["c.1.running_mean"]) * s + sd["c.1.bias"]
-    co = torch.nn.functional.conv1d(A.view(M // seq, seq, Kc).permute(0, 2, 1), wf, bf, padding=2)
-    gate = (torch.tanh(co[:, :half]) * torch.sigmoid(co[:, half:])).permute(0, 2, 1).reshape(M, half)
+    co = torch.nn.functional.conv1d(A.double().view(M // seq, seq, Kc).permute(0, 2, 1), wf.double(), bf.double(), padding=2)
+    gate = (torch.tanh(co[:, :half]) * torch.sigmoid(co[:, half:])).permute(0, 2, 1).reshape(M, half).float()
     res0 = torch.randn((M, half), generator=g)
+    Ad = hip.Pair.split(A, split).to(dev)
+    Wd = packing.to_device(pk["W"], dev, with_lo=split)
+    otol = 3e-5 if split else 1e-2
+
+    def obuf(cols):
+        return hip.Pair(torch.zeros((M, cols), dtype=torch.bfloat16, device=dev),
+                        torch.zeros((M, cols), dtype=torch.bfloat16, device=dev) if split else None)
     for mode in (0, 1, 2):
         res = res0.clone().to(dev)
-        out0 = torch.zeros((M, half + 8), dtype=torch.bfloat16, device=dev)
-        out1 = torch.zeros((M, half), dtype=torch.bfloat16, device=dev)
-        hip.gemm(A.to(torch.bfloat16).to(dev), Kc, M, pk["Kc"], pk["W"].to(dev), pk["N"], pk["bias"].to(dev),
-                 hip.EPI_GATE, out0=out0, ldo0=half + 8, col0=8, taps=5, seq_len=seq, n_valid=half, res=res,
-                 ld_res=half, res_mode=mode, out1=out1, ldo1=half, col1=0)
+        out0, out1 = obuf(half + 8), obuf(half)
+        hip.gemm(Ad, Kc, M, pk["Kc"], Wd, pk["N"], pk["bias"].to(dev), hip.EPI_GATE, out0=out0, ldo0=half + 8, col0=8,
+                 taps=5, seq_len=seq, n_valid=half, res=res, ld_res=half, res_mode=mode, out1=out1, ldo1=half, col1=0)
         torch.cuda.synchronize()
         exp_res = gate if mode == 0 else (res0 + gate if mode == 1 else res0 + 2 * gate)
-        np.testing.assert_allclose(res.cpu().numpy(), exp_res.numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(out0[:, 8:].float().cpu().numpy(), gate.numpy(), rtol=1e-2, atol=1e-2)
-        np.testing.assert_allclose(out1.float().cpu().numpy(), (exp_res + gate).numpy(), rtol=1e-2, atol=1e-2)
+        np.testing.assert_allclose(res.cpu().numpy(), exp_res.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out0.float()[:, 8:].cpu().numpy(), gate.numpy(), rtol=otol, atol=otol)
+        np.testing.assert_allclose(out1.float().cpu().numpy(), (exp_res + gate).numpy(), rtol=otol, atol=otol)
     # rowmap scatter (unpack fused into the epilogue)
-    Wl = _bf16_round(torch.randn((128, Kc), generator=g) / 8)
+    Wl = torch.randn((128, Kc), generator=g) / 8
+    if not split:
+        Wl = _bf16_round(Wl)
     rowmap = torch.arange(M, dtype=torch.int32) * 2
     rowmap[3] = -1
     out = torch.zeros((2 * M, 128), dtype=torch.float32, device=dev)
-    hip.gemm(A.to(torch.bfloat16).to(dev), Kc, M, Kc, Wl.to(torch.bfloat16).to(dev), 128, None, hip.EPI_F32, out0=out,
+    hip.gemm(Ad, Kc, M, Kc, hip.Pair.split(Wl, split).to(dev), 128, None, hip.EPI_F32, out0=out,
              ldo0=128, n_valid=128, rowmap=rowmap.to(dev))
     torch.cuda.synchronize()
-    ref = A @ Wl.t()
+    ref = (A.double() @ Wl.double().t()).float()
     ref[3] = 0
     np.testing.assert_allclose(out.cpu().numpy()[0::2], ref.numpy(), rtol=1e-4, atol=1e-4)
     assert (out.cpu().numpy()[1::2] == 0).all()
@@ -139,22 +163,35 @@ def test_mst_matches_reference_heads(dev, golden_dir):
 
 
 # ------------------------------------------------------------------------------------------
-# whole path against the bf16-contract oracle
+# whole path: bf16x3 against the REFERENCE's outputs (golden) and the fp32 oracle;
+#             bf16 (single pass) against the bf16-contract oracle
 # ------------------------------------------------------------------------------------------
-def _run_case(dev, case, doc_key):
-    from oracle import parser_oracle
+_MODELS = {}
+
+
+def _model(dev, case, precision):
     from cube_amd.networks.parser import Parser
+    key = (case["name"], precision)
+    if key not in _MODELS:
+        cfg, enc, sd = cases.parser_model(case)
+        p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+        p.precision = precision
+        p.load_state_dict(sd)
+        p.to(dev)
+        _MODELS[key] = (p, cfg, enc, sd)
+    return _MODELS[key]
+
+
+def _run_case(dev, case, doc_key, precision):
+    from oracle import parser_oracle
     from cube_amd.networks.utils import MorphoCollate
-    cfg, enc, sd = cases.parser_model(case)
+    p, cfg, enc, sd = _model(dev, case, precision)
     doc = cases.document(case, enc, doc_key)
-    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
-    p.load_state_dict(sd)
-    p.to(dev)
     X = MorphoCollate(enc).collate_fn(doc.sentences)
     X.pop("y_upos")
     r = p.decode_batch(X)
     torch.cuda.synchronize()
-    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="bf16")
+    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="fp32" if precision == "bf16x3" else "bf16")
     torch.set_num_threads(16)
     with torch.no_grad():
         e = ora.decode_batch(parser_oracle.collate(doc.sentences, enc))
@@ -162,7 +199,7 @@ def _run_case(dev, case, doc_key):
 
 
 def _margin_ok(logits_exp, got_idx, exp_idx, tol):
-    """decisions must agree wherever the oracle's top-2 margin exceeds `tol` (absolute)."""
+    """decisions must agree wherever the expected top-2 margin exceeds `tol` (absolute)."""
     flat = logits_exp.reshape(-1, logits_exp.shape[-1])
     gi, ei = got_idx.reshape(-1), exp_idx.reshape(-1)
     top2 = np.sort(flat, axis=-1)[:, -2:]
@@ -171,91 +208,108 @@ def _margin_ok(logits_exp, got_idx, exp_idx, tol):
     return int(bad.sum()), float((gi == ei).mean())
 
 
-@pytest.mark.parametrize("case,doc_key", [
-    (cases.TINY, "equal"), (cases.TINY, "ragged"), (cases.TINY, "single"),
-    (cases.FULL, "full_8x32"), (cases.FULL, "full_2x128"), (cases.FULL, "ragged"),
-])
-def test_parser_batch_matches_oracle(dev, case, doc_key):
-    p, r, e, _ = _run_case(dev, case, doc_key)
+_CASES = [(cases.TINY, "equal", "g2_forward_tiny.npz"), (cases.TINY, "ragged", "g2_forward_tiny.npz"),
+          (cases.TINY, "single", "g2_forward_tiny.npz"), (cases.FULL, "full_8x32", "g3_forward_full.npz"),
+          (cases.FULL, "full_2x128", "g3_forward_full.npz"), (cases.FULL, "ragged", "g3_forward_full.npz")]
+
+
+@pytest.mark.parametrize("case,doc_key,fixture", _CASES)
+def test_parser_bf16x3_matches_reference(dev, golden_dir, case, doc_key, fixture):
+    """Default precision against the reference's OWN outputs (tests/golden, produced by running
+    adobe/NLP-Cube in the build container): arc / label / tag scores within 1e-3 relative,
+    heads / labels / UPOS equal on >= 99.9 % of tokens and wherever the margin exceeds 1e-3."""
+    g = np.load(os.path.join(golden_dir, fixture))
+    p, r, e, _ = _run_case(dev, case, doc_key, "bf16x3")
     sl = r["bt"]["lens"].cpu().numpy()
+    assert (sl == g["%s/sent_len" % doc_key]).all()
     arc = r["arc_logits"].cpu().numpy()
+    ref_arc = g["%s/arc_logits" % doc_key]
+    assert _rel(arc, ref_arc) < REL_TOL, _rel(arc, ref_arc)
     assert _rel(arc, e["arc_logits"]) < REL_TOL
-    probs = r["arc_probs"].cpu().numpy()
-    np.testing.assert_allclose(probs, e["arc_probs"], rtol=5e-3, atol=1e-6)
-    for name, key in (("upos_logits", "upos_logits"),):
-        assert _rel(r[name].cpu().numpy(), e[key]) < REL_TOL, name
+    np.testing.assert_allclose(r["arc_probs"].cpu().numpy(), e["arc_probs"], rtol=2e-3, atol=1e-7)
     n_a = p._sizes["attrs"]
     ax = r["ax_logits"].cpu().numpy()
-    upos_same = (r["upos"].cpu().numpy() == e["upos"])
-    # xpos/attrs are conditioned on the predicted UPOS: compare where it agrees
-    assert _rel(ax[:, :, :n_a][upos_same], e["attrs_logits"][upos_same]) < REL_TOL
-    assert _rel(ax[:, :, n_a:][upos_same], e["xpos_logits"][upos_same]) < REL_TOL
+    assert _rel(r["upos_logits"].cpu().numpy(), g["%s/upos" % doc_key]) < REL_TOL
+    got_upos = r["upos"].cpu().numpy()
+    ref_upos = np.argmax(g["%s/upos" % doc_key], axis=-1)
+    same = got_upos == ref_upos
+    assert _rel(ax[:, :, :n_a][same], g["%s/attrs" % doc_key][same]) < REL_TOL
+    assert _rel(ax[:, :, n_a:][same], g["%s/xpos" % doc_key][same]) < REL_TOL
     mask = np.arange(arc.shape[1])[None, :] < sl[:, None]
-    tol_abs = REL_TOL * np.abs(e["upos_logits"]).max()
-    nbad, agree = _margin_ok(e["upos_logits"][mask], r["upos"].cpu().numpy()[mask], e["upos"][mask], tol_abs)
+    tol_abs = REL_TOL * np.abs(g["%s/upos" % doc_key]).max()
+    nbad, agree = _margin_ok(g["%s/upos" % doc_key][mask], got_upos[mask], ref_upos[mask], tol_abs)
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
-    # heads: the MST of the device probabilities must equal the oracle's tree
+    # heads against the reference's decoded heads
     heads = r["heads"].cpu().numpy()
-    exp_heads = np.zeros_like(heads)
-    for b, h in enumerate(e["heads"]):
-        exp_heads[b, :len(h)] = h
+    ref_heads = g["%s/heads" % doc_key]
     assert (r["status"].cpu().numpy() == 0).all()
-    head_agree = (heads[mask] == exp_heads[mask]).mean()
+    head_agree = (heads[mask] == ref_heads[mask]).mean()
     assert head_agree >= 0.999, head_agree
-    # labels: scores compared where the head agrees
-    same = mask & (heads == exp_heads)
+    # label scores where the head agrees (the reference scored labels for ITS heads)
+    same = mask & (heads == ref_heads)
     lab = r["label_logits"].cpu().numpy()
-    assert _rel(lab[same], e["label_logits"][same]) < REL_TOL
-    tol_abs = REL_TOL * np.abs(e["label_logits"]).max()
-    nbad, agree = _margin_ok(e["label_logits"][same], r["labels"].cpu().numpy()[same], e["labels"][same], tol_abs)
+    ref_lab = g["%s/label_logits" % doc_key]
+    assert _rel(lab[same], ref_lab[same]) < REL_TOL, _rel(lab[same], ref_lab[same])
+    tol_abs = REL_TOL * np.abs(ref_lab).max()
+    nbad, agree = _margin_ok(ref_lab[same], r["labels"].cpu().numpy()[same], np.argmax(ref_lab, -1)[same], tol_abs)
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
 
 
-def test_forward_api_outputs(dev):
+@pytest.mark.parametrize("case,doc_key", [(cases.TINY, "equal"), (cases.TINY, "ragged"), (cases.TINY, "single")])
+def test_parser_bf16_single_pass_matches_bf16_oracle(dev, case, doc_key):
+    """Single-pass bf16 mode against the oracle's bf16 arithmetic contract (small model: the
+    re-quantisation noise that decorrelates two bf16 implementations over 15 layers at full
+    width stays below the tolerance here)."""
+    p, r, e, _ = _run_case(dev, case, doc_key, "bf16")
+    assert _rel(r["arc_logits"].cpu().numpy(), e["arc_logits"]) < REL_TOL
+    assert _rel(r["upos_logits"].cpu().numpy(), e["upos_logits"]) < REL_TOL
+    heads = r["heads"].cpu().numpy()
+    for b, h in enumerate(e["heads"]):
+        np.testing.assert_array_equal(heads[b, :len(h)], h)
+
+
+def test_parser_bf16_single_pass_full_width_is_close(dev):
+    """At full width two bf16 implementations agree only to the bf16 noise floor (1e-2 relative
+    on arc scores); documented in DESIGN.md, this is why bf16x3 is the default."""
+    p, r, e, _ = _run_case(dev, cases.FULL, "full_8x32", "bf16")
+    assert _rel(r["arc_logits"].cpu().numpy(), e["arc_logits"]) < 3e-2
+    assert (r["status"].cpu().numpy() == 0).all()
+
+
+def test_forward_api_outputs(dev, golden_dir):
     """Parser.forward keeps the reference's 8-tuple (parser.py:216) incl. the aux heads."""
-    from oracle import parser_oracle
-    from cube_amd.networks.parser import Parser
     from cube_amd.networks.utils import MorphoCollate
+    g = np.load(os.path.join(golden_dir, "g2_forward_tiny.npz"))
     case = cases.TINY
-    cfg, enc, sd = cases.parser_model(case)
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
     doc = cases.document(case, enc, "ragged")
-    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
-    p.load_state_dict(sd)
-    p.to(dev)
     X = MorphoCollate(enc).collate_fn(doc.sentences)
     X.pop("y_upos")
     outs = p.forward(X)
-    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="bf16")
-    with torch.no_grad():
-        exp = ora.forward(parser_oracle.collate(doc.sentences, enc))
-    names = ("arc", "pre_parsing", "upos", "xpos", "attrs", "aupos", "axpos", "aattrs")
-    for n, a, b in zip(names, outs, exp):
-        assert tuple(a.shape) == tuple(b.shape), n
-        assert _rel(a.cpu().numpy(), b.numpy()) < (REL_TOL if n != "pre_parsing" else 1e-2), n
-    heads = [np.array([0] * int(l)) for l in X["x_sent_len"]]
+    names = ("arc_logits", "pre_parsing", "upos", "xpos", "attrs", "aupos", "axpos", "aattrs")
+    for n, a in zip(names, outs):
+        ref = g["ragged/" + n]
+        assert tuple(a.shape) == tuple(ref.shape), n
+        assert _rel(a.cpu().numpy(), ref) < REL_TOL, (n, _rel(a.cpu().numpy(), ref))
+    sl = g["ragged/sent_len"]
+    heads = [g["ragged/heads"][b, :int(l)] for b, l in enumerate(sl)]
     lab = p._get_labels(outs[1], heads)
-    exp_lab = ora.get_labels(exp[1], heads)
-    assert _rel(lab.cpu().numpy(), exp_lab.numpy()) < 2e-3
+    mask = np.arange(lab.shape[1])[None, :] < sl[:, None]
+    assert _rel(lab.cpu().numpy()[mask], g["ragged/label_logits"][mask]) < REL_TOL
 
 
+@pytest.mark.parametrize("tag,case", [("tiny", cases.TINY), ("full", cases.FULL)])
 @pytest.mark.parametrize("bs", [4, 32])
-def test_process_document_text(dev, bs):
-    """Parser.process end to end: CoNLL-U text equal to the oracle's (bf16 contract) and, for the
-    decisions that are not within rounding of a tie, to the reference's own text (golden G6)."""
-    from oracle import parser_oracle
-    from cube_amd.networks.parser import Parser
+def test_process_document_text_matches_reference(dev, golden_dir, tag, case, bs):
+    """Parser.process end to end against the REFERENCE's CoNLL-U text (golden G6, both batch
+    sizes: results depend on batch composition): >= 99.9 % of the lines identical."""
     from cube_amd.networks.utils import MorphoCollate
-    case = cases.TINY
-    cfg, enc, sd = cases.parser_model(case)
-    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
-    p.load_state_dict(sd)
-    p.to(dev)
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
     doc = cases.document(case, enc, "g6")
     p.process(doc, MorphoCollate(enc), batch_size=bs, num_workers=0)
-    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="bf16")
-    doc2 = cases.document(case, enc, "g6")
-    ora.process(doc2, batch_size=bs)
-    a, b = str(doc).split("\n"), str(doc2).split("\n")
-    assert len(a) == len(b)
-    diff = sum(x != y for x, y in zip(a, b))
-    assert diff <= max(1, len(a) // 1000), diff
+    with open(os.path.join(golden_dir, "g6_process_%s_bs%d.conllu" % (tag, bs)), encoding="utf-8") as f:
+        exp = f.read().split("\n")
+    got = str(doc).split("\n")
+    assert len(got) == len(exp)
+    diff = sum(x != y for x, y in zip(got, exp))
+    assert diff <= len(got) // 1000, diff

@@ -87,11 +87,15 @@ def test_pack_parser_shapes():
     sizes = dict(upos=len(enc.upos2int), xpos=len(enc.xpos2int), attrs=len(enc.attrs2int), labels=len(enc.label2int))
     pk, lay = packing.pack_parser(sd, cfg, sizes, list(cases.TINY["ext"]))
     for cv in pk["char_convs"] + pk["word_convs"]:
-        assert cv["W"].shape == (cv["N"], cv["taps"] * cv["Kc"]) and cv["N"] % 128 == 0 and cv["Kc"] % 32 == 0
-        assert cv["W"].dtype == torch.bfloat16
+        assert cv["W"].hi.shape == (cv["N"], cv["taps"] * cv["Kc"]) and cv["N"] % 128 == 0 and cv["Kc"] % 32 == 0
+        assert cv["W"].hi.dtype == torch.bfloat16 and cv["W"].lo.shape == cv["W"].hi.shape
     rows = packing.lstm_gate_rows(cfg.rnn_size)
     assert sorted(rows[rows >= 0].tolist()) == list(range(4 * cfg.rnn_size))
-    assert pk["lstm"][0]["whh"].shape == (2, len(rows), packing.p32(cfg.rnn_size))
+    assert pk["lstm"][0]["whh"].hi.shape == (2, len(rows), packing.p32(cfg.rnn_size))
+    # hi + lo reproduces the fp32 weight to ~2^-17 relative
+    w = sd["_pre_out.linear_layer.weight"]
+    back = pk["pre_out"]["W"].float()[:w.shape[0], :w.shape[1]]
+    assert float((back - w).abs().max() / w.abs().max()) < 2e-5
     # LSTM bias = b_ih + b_hh, in packed gate order
     b = (sd["_rnn.bias_ih_l0"] + sd["_rnn.bias_hh_l0"]).numpy()
     got = pk["lstm"][0]["ih"]["bias"].numpy()[:len(rows)]
