@@ -40,10 +40,11 @@ const char* cube_last_error(void);
 int cube_abi_version(void);
 
 /* ---- fused bf16 MFMA GEMM / implicit Conv1d(k=taps) ------------------------------------
- * C[r, n] = bias[n] + sum_{tap, c} A[r + tap - taps/2, c] * W[n, tap*Kc + c]
+ * C[r, n] = bias[n] + sum_{tap, c} A[r + tap - taps/2, c] * Wt[n, tap, c]
  * where a row r belongs to the sequence r / seq_len and taps outside it read zeros
- * (Conv1d zero padding).  A: bf16 [M, lda]; W: bf16 [N, taps*Kc] (n-major); Kc % 32 == 0,
- * N % 128 == 0, lda % 8 == 0.  fp32 accumulation. */
+ * (Conv1d zero padding).  A: bf16 [M, lda]; W: bf16 [N, taps*Kc], n-major, K laid out in
+ * 32-channel chunks with the taps of a chunk adjacent: W[n, (kc*taps + tap)*32 + c32] =
+ * Wt[n, tap, kc*32 + c32]; Kc % 32 == 0, N % 128 == 0, lda % 8 == 0.  fp32 accumulation. */
 enum {
   CUBE_EPI_F32 = 0,        /* out0 f32 [M, ldo0]: cols col0..col0+n_valid = C (+= if accumulate)  */
   CUBE_EPI_BF16 = 1,       /* out0 bf16 = C                                                      */

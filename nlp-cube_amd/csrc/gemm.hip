@@ -2,9 +2,12 @@
 //
 // One kernel serves every dense contraction on the parser path: the gated Conv1d(k=5) stacks
 // (5 shifted K-slices of the same activation rows, no im2col), the Linear layers and the LSTM
-// input projections.  128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
-// v_mfma_f32_32x32x16_bf16; BK = 32; A and B tiles register-staged into a double-buffered,
-// padded (80-byte rows: conflict-free ds_read_b128) LDS image; one barrier per K-step.
+// input projections.  Two tile shapes (256x256 / 8 waves for the big convolutions, 128x128 /
+// 4 waves otherwise) over v_mfma_f32_32x32x16_bf16; BK = 32; operands go global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4) into double-buffered images with 64-byte rows whose 16-byte
+// chunks are XOR-swizzled by (row>>2)&3 (conflict-free ds_read_b128 fragment reads; the swizzle
+// rides on the DMA source address); one barrier per K-step.  The activation rows of a tile are
+// staged once per 32-channel chunk and shared by the taps.
 //
 // Precision: operands are bf16, accumulation fp32.  In SPLIT mode ("bf16x3") every operand
 // is a pair of bf16 planes, x ~= hi + lo (16 significant bits), and each product is formed as
@@ -18,10 +21,22 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int ROWB = 80;                      // bytes per LDS row: 64 data + 16 pad
-constexpr int PLANE_BYTES = BM * ROWB;        // one 128-row operand plane
-template <bool SPLIT> constexpr int stage_bytes() { return (SPLIT ? 4 : 2) * PLANE_BYTES; }
+constexpr int BK = 32;
+constexpr int ROWB = 64;  // bytes per LDS row (32 bf16); 16-byte chunks XOR-swizzled by (row>>2)&3
+
+// Tile configurations.  Big: 256x256, 8 waves (2x4), 128x64 per wave — half the LDS fill per MFMA
+// of the small one (the ds_write path, ~79 B/clk/CU, is what bounds a 128x128 tile).  Small:
+// 128x128, 4 waves (2x2), 64x64 per wave, 2 blocks/CU — for the GEMMs with few rows.
+struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4; };
+struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
+
+constexpr int MAX_TAPS = 5;
+// slab rows allocated in LDS: tile rows + halo, rounded to the 16 rows one LDS-DMA piece fills
+template <class C> constexpr int slab_rows() { return (C::BM + MAX_TAPS - 1 + 15) / 16 * 16; }
+// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row]; every buffer holds NP planes
+template <class C, bool SPLIT> constexpr int lds_bytes() {
+  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB;
+}
 
 struct GemmParams {
   const uint16_t* A; const uint16_t* A_lo; int lda; int M; int seq_len; int taps; int Kc;
@@ -45,124 +60,173 @@ __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t id
   }
 }
 
-template <int EPI, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// LDS-DMA: 64 lanes x 16 bytes land at (wave-uniform) l + lane*16; the per-lane SOURCE address
+// carries the swizzle (cdna guide: linear destination + permuted source + permuted read).
+__device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// K loop order: channel chunk kc (32 channels) outer, tap inner; k-step s = kc*taps + tap reads
+// W[n][s*32 .. s*32+32).  For each kc the block stages the A rows [m0 - taps/2, m0 + BM + taps/2)
+// x 32 channels ONCE (the "slab") and the taps read it at shifted rows: the activations cross
+// HBM/L2 -> LDS once per output tile instead of once per tap.  Rows that a tap would take from a
+// neighbouring sequence (Conv1d zero padding) are redirected, per lane, to a zero row in LDS.
+// Both operands go global -> LDS by LDS-DMA (no staging registers, no ds_write), one k-step ahead.
+template <int EPI, bool SPLIT, class C>
+__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = stage_bytes<SPLIT>();
-  constexpr int NP = SPLIT ? 2 : 1;  // planes per operand
+  constexpr int BM = C::BM, BN = C::BN;
+  constexpr int NW = C::WM * C::WN;
+  constexpr int TM = BM / C::WM / 32, TN = BN / C::WN / 32;  // 32x32 MFMA tiles per wave
+  constexpr int NP = SPLIT ? 2 : 1;                          // planes per operand
+  constexpr int SR = slab_rows<C>();
+  constexpr int A_PLANE = SR * ROWB, B_PLANE = BN * ROWB;
+  constexpr int A_BUF = NP * A_PLANE, B_BUF = NP * B_PLANE;
+  constexpr int B_BASE = 2 * A_BUF;
+  constexpr int ZERO_OFF = 2 * A_BUF + 2 * B_BUF;
+  constexpr int A_PIECES = SR / 16, B_PIECES = BN / 16;      // 1-KiB DMA pieces per plane
+  constexpr int PA = (A_PIECES + NW - 1) / NW, PB = B_PIECES / NW;
+  static_assert(TN == 2, "the gate epilogue pairs the two 32-column tiles of a wave");
+  static_assert(B_PIECES % NW == 0, "B pieces must divide over the waves");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / C::WN, wc = wid % C::WN;
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
-  const int ksteps_per_tap = p.Kc / BK;
-  const int nk = p.taps * ksteps_per_tap;
-  const int ktot = p.taps * p.Kc;
-  const int half_taps = p.taps >> 1;
+  const int taps = p.taps;
+  const int half_taps = taps >> 1;
+  const int nkc = p.Kc / BK;
+  const int nk = nkc * taps;
+  const int ktot = taps * p.Kc;
 
-  // staging: 512 16-byte chunks per operand plane, 2 per thread: chunk = tid + 256*i
-  int a_pos[2];
-  size_t a_off[2], b_off[2];
+  if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
+
+  // ---- DMA source offsets (elements) of this lane for the pieces its wave issues
+  size_t a_src[PA], b_src[PB];
+  {
+    const int prow = lane >> 2, ppos = lane & 3;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int chunk = tid + 256 * i;
-    const int row = chunk >> 2;
-    const int kc8 = (chunk & 3) * 8;
-    const int r = m0 + row;
-    a_pos[i] = (r < p.M) ? (r % p.seq_len) : -100000;
-    a_off[i] = (size_t)r * p.lda + kc8;
-    b_off[i] = (size_t)(n0 + row) * ktot + kc8;
+    for (int i = 0; i < PA; ++i) {
+      const int row = 16 * (wid + NW * i) + prow;           // slab row
+      long g = (long)m0 - half_taps + row;                  // global activation row, clamped: rows
+      g = g < 0 ? 0 : (g >= p.M ? p.M - 1 : g);             // outside [0, M) are never read unmasked
+      a_src[i] = (size_t)g * p.lda + ((ppos ^ ((row >> 2) & 3)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int row = 16 * (wid + NW * i) + prow;
+      b_src[i] = (size_t)(n0 + row) * ktot + ((ppos ^ ((row >> 2) & 3)) << 3);
+    }
   }
-  const int st_off0 = (tid >> 2) * ROWB + (tid & 3) * 16;          // chunk tid
-  const int st_off1 = ((tid + 256) >> 2) * ROWB + (tid & 3) * 16;  // chunk tid+256
 
-  uint4 ra[NP][2], rb[NP][2];
-  auto load_step = [&](int s) {
-    const int tap = s / ksteps_per_tap;
-    const int kc0 = (s - tap * ksteps_per_tap) * BK;
-    const int d = tap - half_taps;
-    const long a_delta = (long)d * p.lda + kc0;
+  // ---- per-lane fragment rows and tap validity (bit t of vmask[i]: tap t reads a real row)
+  const int l31 = lane & 31, lh = lane >> 5;
+  int a_row[TM];
+  unsigned vmask[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pp = a_pos[i] + d;
-      const bool ok = (pp >= 0 && pp < p.seq_len);
-      ra[0][i] = ok ? *reinterpret_cast<const uint4*>(p.A + a_off[i] + a_delta) : make_uint4(0, 0, 0, 0);
-      rb[0][i] = *reinterpret_cast<const uint4*>(p.W + b_off[i] + (size_t)s * BK);
-      if constexpr (SPLIT) {
-        ra[1][i] = ok ? *reinterpret_cast<const uint4*>(p.A_lo + a_off[i] + a_delta) : make_uint4(0, 0, 0, 0);
-        rb[1][i] = *reinterpret_cast<const uint4*>(p.W_lo + b_off[i] + (size_t)s * BK);
-      }
+  for (int i = 0; i < TM; ++i) {
+    const int lr = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
+    a_row[i] = lr;
+    const int r = m0 + lr;
+    const int pos = r % p.seq_len;
+    unsigned m = 0;
+    for (int t = 0; t < taps; ++t) {
+      const int pp = pos + t - half_taps;
+      if (r < p.M && pp >= 0 && pp < p.seq_len) m |= 1u << t;
     }
-  };
-  // stage layout: [A hi][A lo][B hi][B lo] (SPLIT) or [A][B]
-  auto store_step = [&](int buf) {
-    unsigned char* base = smem + buf * STAGE;
+    vmask[i] = m;
+  }
+  int b_rd[TN][2];
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-      *reinterpret_cast<uint4*>(base + pl * PLANE_BYTES + st_off0) = ra[pl][0];
-      *reinterpret_cast<uint4*>(base + pl * PLANE_BYTES + st_off1) = ra[pl][1];
-      *reinterpret_cast<uint4*>(base + (NP + pl) * PLANE_BYTES + st_off0) = rb[pl][0];
-      *reinterpret_cast<uint4*>(base + (NP + pl) * PLANE_BYTES + st_off1) = rb[pl][1];
-    }
-  };
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_rd[j][ks] = lds_off(wc * (BN / C::WN) + j * 32 + l31, 2 * ks + lh);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_step(0);
-  store_step(0);
+#define ISSUE_A(KC, BUF)                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_) {                                         \
+    const int q_ = wid + NW * i_;                                                             \
+    if (q_ < A_PIECES) {                                                                      \
+      unsigned char* l_ = smem + (BUF) * A_BUF + q_ * 1024;                                   \
+      glds16(p.A + a_src[i_] + (KC) * BK, l_);                                                \
+      if constexpr (SPLIT) glds16(p.A_lo + a_src[i_] + (KC) * BK, l_ + A_PLANE);              \
+    }                                                                                         \
+  }
+#define ISSUE_B(S, BUF)                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_) {                                         \
+    unsigned char* l_ = smem + B_BASE + (BUF) * B_BUF + (wid + NW * i_) * 1024;               \
+    glds16(p.W + b_src[i_] + (size_t)(S) * BK, l_);                                           \
+    if constexpr (SPLIT) glds16(p.W_lo + b_src[i_] + (size_t)(S) * BK, l_ + B_PLANE);         \
+  }
+
+  ISSUE_A(0, 0)
+  ISSUE_B(0, 0)
   __syncthreads();
 
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int a_rd = (wr * 64 + l31) * ROWB + lh * 16;
-  const int b_rd = NP * PLANE_BYTES + (wc * 64 + l31) * ROWB + lh * 16;
-
+  int kc = 0, tap = 0;
   for (int s = 0; s < nk; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nk) load_step(s + 1);
-    const unsigned char* base = smem + buf * STAGE;
+    const bool last_tap = (tap == taps - 1);
+    if (s + 1 < nk) {
+      ISSUE_B(s + 1, (s + 1) & 1)
+      if (last_tap) { ISSUE_A(kc + 1, (kc + 1) & 1) }
+    }
+    const unsigned char* abase = smem + (kc & 1) * A_BUF;
+    const unsigned char* bbase = smem + B_BASE + (s & 1) * B_BUF;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[NP][2], fb[NP][2];
+      bf16x8 fb[NP][TN];
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE_BYTES + a_rd + i * 32 * ROWB + ks * 32);
-          fb[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE_BYTES + b_rd + i * 32 * ROWB + ks * 32);
-        }
+        for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][ks]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i) {
+        const int row = a_row[i] + tap;  // slab row of this lane's output row shifted by the tap
+        const bool ok = (vmask[i] >> tap) & 1u;
+        const unsigned char* ap = ok ? abase + lds_off(row, 2 * ks + lh) : smem + ZERO_OFF;
+        bf16x8 fa[NP];
+        fa[0] = *reinterpret_cast<const bf16x8*>(ap);
+        if constexpr (SPLIT) fa[1] = *reinterpret_cast<const bf16x8*>(ok ? ap + A_PLANE : ap);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
           if constexpr (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1][j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0][j], acc[i][j], 0, 0, 0);
         }
+      }
     }
-    if (s + 1 < nk) store_step(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
+    if (last_tap) { tap = 0; ++kc; } else { ++tap; }
   }
+#undef ISSUE_A
+#undef ISSUE_B
 
   // ---- epilogue.  C/D map of 32x32x16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int wrow0 = m0 + wr * (BM / C::WM);
+  const int wcol0 = n0 + wc * (BN / C::WN);
   if constexpr (EPI == CUBE_EPI_GATE) {
-    const int ch = blockIdx.x * 64 + wc * 32 + l31;
-    const float bias_a = p.bias[n0 + wc * 64 + l31];
-    const float bias_b = p.bias[n0 + wc * 64 + 32 + l31];
+    const int ch = wcol0 / 2 + l31;
+    const float bias_a = p.bias[wcol0 + l31];
+    const float bias_b = p.bias[wcol0 + 32 + l31];
     uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.M && ch < p.n_valid) {
           const float g = tanhf_(acc[i][0][r] + bias_a) * sigmoidf_(acc[i][1][r] + bias_b);
           float* rp = p.res + (size_t)row * p.ld_res + ch;
@@ -179,15 +243,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int col = wcol0 + j * 32 + l31;
       if (col >= p.n_valid) continue;
       const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (row >= p.M) continue;
           int orow = row;
           if (p.rowmap) {
@@ -209,24 +273,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-template <int EPI>
-int launch(const GemmParams& p, dim3 grid, hipStream_t st) {
-  if (p.A_lo) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)gemm_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * stage_bytes<true>()) != hipSuccess)
-        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", 2 * stage_bytes<true>());
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel<EPI, true>), grid, dim3(256), 2 * stage_bytes<true>(), st, p);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<EPI, false>), grid, dim3(256), 2 * stage_bytes<false>(), st, p);
+template <int EPI, bool SPLIT, class C>
+int launch_cfg(const GemmParams& p, hipStream_t st) {
+  constexpr int lds = lds_bytes<C, SPLIT>();
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_kernel<EPI, SPLIT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
+    attr_set = true;
   }
+  dim3 grid(p.N / C::BN, (p.M + C::BM - 1) / C::BM);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p);
   return CUBE_OK;
 }
+
+template <int EPI>
+int launch(const GemmParams& p, hipStream_t st) {
+  // the big tile needs enough row tiles to fill the 256 CUs
+  const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
+  if (p.A_lo) return big ? launch_cfg<EPI, true, CfgBig>(p, st) : launch_cfg<EPI, true, CfgSmall>(p, st);
+  return big ? launch_cfg<EPI, false, CfgBig>(p, st) : launch_cfg<EPI, false, CfgSmall>(p, st);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -238,7 +308,7 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: A_lo and W_lo must be given together (bf16x3) or not at all (bf16)");
   if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: taps=%d", a->taps);
   if (a->Kc <= 0 || a->Kc % BK) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BK);
-  if (a->N <= 0 || a->N % BN) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of %d", a->N, BN);
+  if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of 128", a->N);
   if (a->lda < a->Kc || a->lda % 8) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
   if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->A_lo) || !aligned16(a->W_lo))
     CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: operands must be 16-byte aligned");
@@ -255,21 +325,20 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   p.out1 = (uint16_t*)a->out1; p.out1_lo = (uint16_t*)a->out1_lo; p.ldo1 = a->ldo1; p.col1 = a->col1;
   p.out2 = (uint16_t*)a->out2; p.out2_lo = (uint16_t*)a->out2_lo; p.ldo2 = a->ldo2; p.col2 = a->col2;
   if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: n_valid=%d > N=%d", p.n_valid, a->N);
-  dim3 grid(a->N / BN, (a->M + BM - 1) / BM);
   hipStream_t st = (hipStream_t)stream;
   int rc = CUBE_OK;
   switch (a->epilogue) {
     case CUBE_EPI_F32:
       if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
-      rc = launch<CUBE_EPI_F32>(p, grid, st);
+      rc = launch<CUBE_EPI_F32>(p, st);
       break;
     case CUBE_EPI_BF16:
     case CUBE_EPI_BF16_TANH:
     case CUBE_EPI_BF16_RELU:
       if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
-      if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, grid, st);
-      else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, grid, st);
-      else rc = launch<CUBE_EPI_BF16_RELU>(p, grid, st);
+      if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, st);
+      else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, st);
+      else rc = launch<CUBE_EPI_BF16_RELU>(p, st);
       break;
     case CUBE_EPI_GATE: {
       const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile
@@ -281,7 +350,7 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
       if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out1/ldo1");
       if (a->out2 && a->ldo2 < a->col2 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out2/ldo2");
       if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
-      rc = launch<CUBE_EPI_GATE>(p, grid, st);
+      rc = launch<CUBE_EPI_GATE>(p, st);
       break;
     }
     default:

@@ -86,6 +86,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CubeHipError("libcubehip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the parser path)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so); it must be in the process
+    # before this library resolves its libamdhip64 dependency, or two runtimes end up loaded and
+    # device pointers from one are unknown to the other ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -77,7 +77,9 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0):
     tmp[:, :, valid_k] = sub.permute(0, 2, 1)
     W[valid_n] = tmp
     bias[valid_n] = b[src_n]
-    return dict(W=_bf16(W.reshape(N, taps * Kc)), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
+    # K order of cube_gemm_bf16: 32-channel chunk outer, tap inner
+    W = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)
+    return dict(W=_bf16(W), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
 
 
 def pack_linear(w, b, in_perm=None, out_rows=None, n_pad=None):

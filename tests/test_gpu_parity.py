@@ -39,6 +39,7 @@ def _bf16_round(x):
 @pytest.mark.parametrize("M,seq,taps,Kc,N,epi", [
     (300, 300, 1, 64, 128, "f32"), (257, 257, 1, 352, 256, "tanh"), (4 * 33, 33, 5, 96, 128, "relu"),
     (7 * 13, 13, 5, 32, 128, "bf16"), (1000, 1000, 1, 512, 384, "f32"),
+    (13 * 1975, 13, 5, 64, 512, "f32"), (13 * 1975, 13, 5, 64, 512, "tanh"),  # 256x256-tile configuration
 ])
 def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
     """bf16 (one pass, operands already bf16-exact) and bf16x3 (hi/lo planes of arbitrary fp32
@@ -70,7 +71,8 @@ def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
         ref = torch.relu(ref)
     ref = ref.float()
     n_valid = N - 5
-    Ad, Wd, bd = hip.Pair.split(A, split).to(dev), hip.Pair.split(W, split).to(dev), bias.to(dev)
+    Wk = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)  # kernel K order
+    Ad, Wd, bd = hip.Pair.split(A, split).to(dev), hip.Pair.split(Wk, split).to(dev), bias.to(dev)
     code = dict(f32=hip.EPI_F32, bf16=hip.EPI_BF16, tanh=hip.EPI_BF16_TANH, relu=hip.EPI_BF16_RELU)[epi]
     ldo = N + 8
     if epi == "f32":
@@ -90,11 +92,11 @@ def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_gemm_gate_epilogue_and_rowmap(dev, split):
+@pytest.mark.parametrize("M,seq,Kc,half", [(6 * 11, 11, 64, 80), (11 * 2400, 11, 64, 256)])  # small / 256x256 tiles
+def test_gemm_gate_epilogue_and_rowmap(dev, split, M, seq, Kc, half):
     from cube_amd import hip
     from cube_amd.networks import packing
     g = torch.Generator().manual_seed(5)
-    M, seq, Kc, half = 6 * 11, 11, 64, 80
     A = torch.randn((M, Kc), generator=g)
     if not split:
         A = _bf16_round(A)
@@ -113,7 +115,7 @@ def test_gemm_gate_epilogue_and_rowmap(dev, split):
     res0 = torch.randn((M, half), generator=g)
     Ad = hip.Pair.split(A, split).to(dev)
     Wd = packing.to_device(pk["W"], dev, with_lo=split)
-    otol = 3e-5 if split else 1e-2
+    otol = 1e-4 if split else 1e-2
 
     def obuf(cols):
         return hip.Pair(torch.zeros((M, cols), dtype=torch.bfloat16, device=dev),
@@ -125,7 +127,7 @@ def test_gemm_gate_epilogue_and_rowmap(dev, split):
                  taps=5, seq_len=seq, n_valid=half, res=res, ld_res=half, res_mode=mode, out1=out1, ldo1=half, col1=0)
         torch.cuda.synchronize()
         exp_res = gate if mode == 0 else (res0 + gate if mode == 1 else res0 + 2 * gate)
-        np.testing.assert_allclose(res.cpu().numpy(), exp_res.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(res.cpu().numpy(), exp_res.numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(out0.float()[:, 8:].cpu().numpy(), gate.numpy(), rtol=otol, atol=otol)
         np.testing.assert_allclose(out1.float().cpu().numpy(), (exp_res + gate).numpy(), rtol=otol, atol=otol)
     # rowmap scatter (unpack fused into the epilogue)
