@@ -61,7 +61,7 @@ enum {
  * CUBE_EPI_GATE: N = 2*half output channels packed so that column
  *   n = nb*128 + wc*64 + part*32 + j  holds channel (part ? half : 0) + nb*64 + wc*32 + j;
  * g = tanh(C_a) * sigmoid(C_b) per channel ch.  Then
- *   res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g (and nothing else)
+ *   res (optional) res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g
  *   out0 (bf16, optional): [row, col0+ch] = g
  *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference) */
 typedef struct cube_gemm_args {
@@ -80,8 +80,13 @@ int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* table, int ld_table,
                      const int32_t* idx, const int32_t* dst_rows, int n, void* stream);
 
-/* out[n, c] = bf16( sum_{p < len[n]} x[n*W + p, c] / max(len[n], 1) ),  x f32 [N*W, ld_x], c < C */
-int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C,
+/* WordGram tail: out[n, c] = bf16( sum_k weight[k] * sum_{p < len[n]} x_k[n*W + p, c] / max(len[n], 1) )
+ * over the n_layers gated-layer outputs x_k (bf16 [N*W, ld_x], hi [+ lo] planes); x_hi / x_lo /
+ * weight are HOST arrays of n_layers entries (x_lo may be NULL).  With weight = 1,..,1,2 this is
+ * the reference's (x + res) masked mean, res = sum of all layers, x = the last one.              */
+#define CUBE_MAX_MEAN_LAYERS 8
+int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                     int ld_x, const int32_t* len, int N, int W, int C,
                      void* out, void* out_lo, int ld_out, void* stream);
 
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);

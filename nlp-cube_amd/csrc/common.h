@@ -33,9 +33,10 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) 
   hi = f32_to_bf16(v);
   lo = f32_to_bf16(v - bf16_to_f32(hi));
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 forms (1 ulp each): absolute error < 3e-7 on (-1, 1) outputs, exact limits
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error < 2e-7
-  float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
+  // tanh(x) = 1 - 2/(exp(2x)+1)
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }

@@ -16,6 +16,7 @@
 //
 // Epilogues are fused: bias, tanh / relu, the tanh*sigmoid gate with residual accumulation,
 // row scatter (unpack), hi/lo splitting of bf16 outputs.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/cube_hip.h"
 
@@ -47,6 +48,7 @@ struct GemmParams {
   float* res; int ld_res; int res_mode;
   uint16_t* out1; uint16_t* out1_lo; int ldo1; int col1;
   uint16_t* out2; uint16_t* out2_lo; int ldo2; int col2;
+  int dbg;
 };
 
 __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t idx, float v) {
@@ -178,34 +180,52 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   for (int s = 0; s < nk; ++s) {
     const bool last_tap = (tap == taps - 1);
     if (s + 1 < nk) {
-      ISSUE_B(s + 1, (s + 1) & 1)
-      if (last_tap) { ISSUE_A(kc + 1, (kc + 1) & 1) }
+      if (!(p.dbg & 1)) { ISSUE_B(s + 1, (s + 1) & 1) }
+      if (last_tap && !(p.dbg & 2)) { ISSUE_A(kc + 1, (kc + 1) & 1) }
     }
-    const unsigned char* abase = smem + (kc & 1) * A_BUF;
+    if (p.dbg & 4) { __syncthreads(); if (last_tap) { tap = 0; ++kc; } else { ++tap; } continue; }
     const unsigned char* bbase = smem + B_BASE + (s & 1) * B_BUF;
+    // fragment reads run one (k-substep, row tile) unit ahead of the MFMAs that consume them
+    int aoff[TM], alo[TM];  // LDS byte offsets of this lane's A fragment (k-substep 0) and hi->lo distance
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fb[NP][TN];
+    for (int i = 0; i < TM; ++i) {
+      const bool ok = (vmask[i] >> tap) & 1u;
+      const int row = a_row[i] + tap;  // slab row of this lane's output row shifted by the tap
+      aoff[i] = ok ? (kc & 1) * A_BUF + lds_off(row, lh) : ZERO_OFF;
+      alo[i] = ok ? A_PLANE : 0;
+    }
+    bf16x8 fb[2][NP][TN];
+    bf16x8 fa[2][NP];
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][ks]);
+      for (int j = 0; j < TN; ++j) fb[0][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][0]);
+    fa[0][0] = *reinterpret_cast<const bf16x8*>(smem + aoff[0]);
+    if constexpr (SPLIT) fa[0][1] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + alo[0]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = a_row[i] + tap;  // slab row of this lane's output row shifted by the tap
-        const bool ok = (vmask[i] >> tap) & 1u;
-        const unsigned char* ap = ok ? abase + lds_off(row, 2 * ks + lh) : smem + ZERO_OFF;
-        bf16x8 fa[NP];
-        fa[0] = *reinterpret_cast<const bf16x8*>(ap);
-        if constexpr (SPLIT) fa[1] = *reinterpret_cast<const bf16x8*>(ok ? ap + A_PLANE : ap);
+    for (int u = 0; u < 2 * TM; ++u) {
+      const int ks = u / TM, i = u % TM;
+      if (u + 1 < 2 * TM) {  // prefetch the next unit's A fragments (and, once, the second k-substep's B)
+        const int ks2 = (u + 1) / TM, i2 = (u + 1) % TM;
+        // chunk = (2*ks + lh) ^ swz: the k-substep toggles bit 1 of the chunk index = offset ^ 32
+        const int o = aoff[i2] ^ (ks2 ? 32 : 0);
+        fa[(u + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + o);
+        if constexpr (SPLIT) fa[(u + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + o + alo[i2]);
+        if (u + 1 == TM) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1][j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0][j], acc[i][j], 0, 0, 0);
+          for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              fb[1][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][1]);
         }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (SPLIT) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][1][j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
@@ -221,21 +241,29 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     const int ch = wcol0 / 2 + l31;
     const float bias_a = p.bias[wcol0 + l31];
     const float bias_b = p.bias[wcol0 + 32 + l31];
-    uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out0);
+    float* __restrict__ res = p.res;
+    uint16_t* __restrict__ out0 = reinterpret_cast<uint16_t*>(p.out0);
+    uint16_t* __restrict__ out0_lo = p.out0_lo;
+    const bool ch_ok = ch < p.n_valid;
+    const int res_mode = p.res_mode;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      // all residual loads of this 32-row tile first (independent, in flight together), then the math
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M && ch < p.n_valid) {
+        rv[r] = (res && res_mode != 0 && ch_ok && row < p.M) ? res[(size_t)row * p.ld_res + ch] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M && ch_ok) {
           const float g = tanhf_(acc[i][0][r] + bias_a) * sigmoidf_(acc[i][1][r] + bias_b);
-          float* rp = p.res + (size_t)row * p.ld_res + ch;
-          float rs;
-          if (p.res_mode == 0) rs = g;
-          else if (p.res_mode == 1) rs = *rp + g;
-          else rs = *rp + 2.0f * g;
-          *rp = rs;
-          if (out0) store_bf16(out0, p.out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
+          if (out0) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
+          if (!res) continue;  // plain gated layer: no residual stream
+          const float rs = rv[r] + (res_mode == 2 ? 2.0f * g : g);
+          res[(size_t)row * p.ld_res + ch] = rs;
           if (p.out1) store_bf16(p.out1, p.out1_lo, (size_t)row * p.ldo1 + p.col1 + ch, rs + g);
           if (p.out2) store_bf16(p.out2, p.out2_lo, (size_t)row * p.ldo2 + p.col2 + ch, rs + g);
         }
@@ -323,6 +351,7 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   p.out0 = a->out0; p.out0_lo = (uint16_t*)a->out0_lo; p.ldo0 = a->ldo0; p.col0 = a->col0; p.rowmap = a->rowmap;
   p.res = a->res; p.ld_res = a->ld_res; p.res_mode = a->res_mode;
   p.out1 = (uint16_t*)a->out1; p.out1_lo = (uint16_t*)a->out1_lo; p.ldo1 = a->ldo1; p.col1 = a->col1;
+  { const char* e = getenv("CUBE_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.out2 = (uint16_t*)a->out2; p.out2_lo = (uint16_t*)a->out2_lo; p.ldo2 = a->ldo2; p.col2 = a->col2;
   if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: n_valid=%d > N=%d", p.n_valid, a->N);
   hipStream_t st = (hipStream_t)stream;
@@ -343,7 +372,9 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
     case CUBE_EPI_GATE: {
       const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile
       if (half > a->N / 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate n_valid=%d > N/2", half);
-      if (!a->res || a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs res[M, >=%d]", half);
+      if (a->res && a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs res[M, >=%d]", half);
+      if (!a->res && (a->out1 || a->out2)) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: out1/out2 (x + res) need res");
+      if (!a->res && !a->out0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue without any output");
       if (a->res_mode < 0 || a->res_mode > 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: res_mode=%d", a->res_mode);
       if (a->rowmap) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: rowmap is not supported by the gate epilogue");
       if (a->out0 && a->ldo0 < a->col0 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");

@@ -42,8 +42,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, int ld_
   }
 }
 
-// ---- masked mean over the W character positions of each word
-__global__ __launch_bounds__(256) void masked_mean_kernel(const float* x, int ld_x, const int32_t* len, int N, int W,
+// ---- masked mean over the W character positions of each word, summed over the gated layers
+struct MeanLayers {
+  const uint16_t* hi[CUBE_MAX_MEAN_LAYERS];
+  const uint16_t* lo[CUBE_MAX_MEAN_LAYERS];
+  float weight[CUBE_MAX_MEAN_LAYERS];
+  int n;
+};
+__global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
                                                           int C, uint16_t* out, uint16_t* out_lo, int ld_out) {
   const int n = blockIdx.x;
   if (n >= N) return;
@@ -51,8 +57,16 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* x, int ld
   const float den = (float)max(len[n], 1);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
-    const float* p = x + (size_t)n * W * ld_x + c;
-    for (int q = 0; q < l; ++q) s += p[(size_t)q * ld_x];
+    for (int k = 0; k < ly.n; ++k) {
+      const size_t base = (size_t)n * W * ld_x + c;
+      float sk = 0.f;
+      for (int q = 0; q < l; ++q) {
+        float v = bf16_to_f32(ly.hi[k][base + (size_t)q * ld_x]);
+        if (ly.lo[k]) v += bf16_to_f32(ly.lo[k][base + (size_t)q * ld_x]);
+        sk += v;
+      }
+      s += ly.weight[k] * sk;
+    }
     const float v = s / den;
     if (out_lo) {
       uint16_t h, lo;
@@ -124,11 +138,21 @@ extern "C" int cube_gather_rows(void* dst, int ld_dst, int col0, int width, cons
   return CUBE_OK;
 }
 
-extern "C" int cube_masked_mean(const float* x, int ld_x, const int32_t* len, int N, int W, int C, void* out,
-                                void* out_lo, int ld_out, void* stream) {
+extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                                int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
+                                void* stream) {
   if (N <= 0) return CUBE_OK;
-  if (!x || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ld_x, len, N, W, C,
+  if (!x_hi || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
+  if (n_layers <= 0 || n_layers > CUBE_MAX_MEAN_LAYERS) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: n_layers=%d (max %d)", n_layers, CUBE_MAX_MEAN_LAYERS);
+  MeanLayers ly;
+  ly.n = n_layers;
+  for (int k = 0; k < CUBE_MAX_MEAN_LAYERS; ++k) {
+    ly.hi[k] = k < n_layers ? (const uint16_t*)x_hi[k] : nullptr;
+    ly.lo[k] = (k < n_layers && x_lo) ? (const uint16_t*)x_lo[k] : nullptr;
+    ly.weight[k] = (k < n_layers && weight) ? weight[k] : 1.0f;
+    if (k < n_layers && !ly.hi[k]) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: null layer %d", k);
+  }
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ly, ld_x, len, N, W, C,
                      (uint16_t*)out, (uint16_t*)out_lo, ld_out);
   CUBE_CHECK_LAUNCH("cube_masked_mean");
   return CUBE_OK;

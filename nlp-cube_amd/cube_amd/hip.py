@@ -57,7 +57,8 @@ SIGNATURES = {
     "cube_abi_version": (c_int, []),
     "cube_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "cube_gather_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "cube_masked_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_int, c_void_p]),
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -148,3 +149,13 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     a.out2, a.out2_lo = _planes(out2)
     a.ldo2, a.col2 = ldo2, col2
     check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")
+
+
+def masked_mean(layers, weights, ld_x, word_len, N, W, C, out, ld_out, stream=None):
+    """layers: list of Pair [N*W, ld_x]; out: Pair [N, ld_out]."""
+    n = len(layers)
+    his = (c_void_p * n)(*[l.hi.data_ptr() for l in layers])
+    los = (c_void_p * n)(*[l.lo.data_ptr() for l in layers]) if layers[0].lo is not None else None
+    ws = (ctypes.c_float * n)(*weights)
+    check(load().cube_masked_mean(his, los, ws, n, ld_x, word_len.data_ptr(), N, W, C, out.hi.data_ptr(), ptr(out.lo),
+                                  ld_out, stream if stream is not None else stream_handle()), "cube_masked_mean")

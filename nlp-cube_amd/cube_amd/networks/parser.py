@@ -211,31 +211,24 @@ class Parser:
 
         # ---- character level (WordGram, modules.py:450-484)
         xc0 = buf.get("xc0", NW, lay.xc0_w)
-        xca, xcb = buf.get("xca", NW, lay.xc_w), buf.get("xcb", NW, lay.xc_w)
-        resc = buf.get("resc", NW, ch, torch.float32)
         gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, NW)
         gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, NW)
         gather(xc0, lay.xc0_w, lay.xc0_lang, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
         nchar = len(pk["char_convs"])
-        if nchar > 1:
-            gather(xca, lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
-        if nchar > 2:
-            gather(xcb, lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
+        # every gated layer keeps its own output g_l = [g | lang]: the next layer reads it, and the
+        # masked mean sums them (no fp32 residual stream through HBM at N*W rows)
+        gl = [buf.get("xc_g%d" % l, NW, lay.xc_w) for l in range(nchar)]
         src, src_ld = xc0, lay.xc0_w
         for l, cv in enumerate(pk["char_convs"]):
-            last = l == nchar - 1
-            dst = None if last else (xca if l % 2 == 0 else xcb)
+            if l + 1 < nchar:
+                gather(gl[l], lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
             with self._timed("char_conv" if l > 0 else "char_conv0"):
-                hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst,
-                         ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], res=resc, ld_res=ch,
-                         res_mode=(0 if l == 0 else (2 if last else 1)) if nchar > 1 else 0, stream=st)
-            src, src_ld = dst, lay.xc_w
-        if nchar == 1:
-            resc[:NW * ch].mul_(2.0)  # single layer: x + res = 2 g
+                hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
+                         ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], stream=st)
+            src, src_ld = gl[l], lay.xc_w
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
-        hip.check(lib.cube_masked_mean(resc.data_ptr(), ch, bt["word_len"].data_ptr(), N, W, ch, pool.hi.data_ptr(),
-                                       lo(pool.lo), pool_w, st), "cube_masked_mean")
+        hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w, stream=st)
         # ---- word level input XW0 = [word | char | lang | ext], root row = _r_emb
         xw0 = buf.get("xw0", BT, lay.xw0_w)
         self._zero(xw0, BT * lay.xw0_w)

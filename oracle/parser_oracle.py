@@ -155,10 +155,12 @@ class _Net:
             else:
                 co = self.conv_bn(torch.cat([x, xl], dim=1), pre, half if skip is not None else 0)
             tmp = torch.tanh(co[:, :half, :]) * torch.sigmoid(co[:, half:, :])
-            res = tmp if res is None else res + tmp
+            # bf16 contract: the HIP path has no fp32 residual stream at this level; the masked
+            # mean sums the stored (rounded) layer outputs.  fp32 mode: q is the identity.
+            res = self.q(tmp) if res is None else res + self.q(tmp)
             skip = tmp
             x = tmp
-        x = (x + res).permute(0, 2, 1)
+        x = (self.q(x) + res).permute(0, 2, 1)
         x = x * x_mask.unsqueeze(2)  # float64 mask promotes the product (utils.py:247)
         pre = torch.sum(x, dim=1, dtype=torch.float)
         norm = pre / torch.clip(x_word_len.unsqueeze(1), min=1)
