@@ -101,7 +101,8 @@ int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* ou
 /* One bidirectional LSTM layer's recurrence over a padded batch.
  * gx f32 [B*T, 2*G] (G = 64*U, U = ceil(H/16)): input projections + both biases, gate columns
  *   packed as dir*G + u*64 + gate*16 + j for hidden unit u*16+j (gate order i,f,g,o).
- * whh bf16 [2][G][KH] (KH = 32*ceil(H/32)): recurrent weights, row = packed gate column.
+ * whh bf16 [2][U][4][KS][64][8] (KS = ceil(H/32)): recurrent weights in MFMA-fragment order:
+ *   element [d][u][g][ks][lane][j] = W_hh_d[g*H + u*16 + (lane&15)][ks*32 + (lane>>4)*8 + j] (0 beyond H).
  * out bf16 [B*T, ld_out]: h_fwd -> cols [col0, col0+H), h_bwd -> [col0+H, col0+2H).        */
 int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, int B, int T, int H,
                           void* out, void* out_lo, int ld_out, int col0, void* stream);

@@ -37,7 +37,8 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
   for (int i = threadIdx.x * 4; i < 2 * NP * HIMG; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(smem + i) = 0u;
   __syncthreads();
 
-  const size_t woff = ((size_t)dir * G + (size_t)u * 64 + l15) * KH + lq * 8;
+  // fragment-major weights: [dir][u][gate][k-step][lane][8]: every wave-level load is 1 KiB contiguous
+  const size_t woff = (((size_t)dir * U + u) * 4 * KSTEPS) * 512 + lane * 8;
   const uint16_t* wbase = whh + woff;
   const uint16_t* wbase_lo = SPLIT ? whh_lo + woff : nullptr;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
@@ -85,9 +86,9 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
       if constexpr (SPLIT) al = *reinterpret_cast<const bf16x8*>(hb + HIMG + ks * 64);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + (size_t)g * 16 * KH + ks * 32);
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + (g * KSTEPS + ks) * 512);
         if constexpr (SPLIT) {
-          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + (size_t)g * 16 * KH + ks * 32);
+          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + (g * KSTEPS + ks) * 512);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w2, acc[g], 0, 0, 0);
         }

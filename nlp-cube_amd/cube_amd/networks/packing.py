@@ -230,7 +230,11 @@ def pack_parser(sd, cfg, enc_sizes, ext_dims):
             hh.append(wp)
         out_rows = np.concatenate([rows1, np.where(rows1 >= 0, rows1 + 4 * H, -1)])
         ih = pack_linear(torch.cat(ws, 0), torch.cat(bs, 0), in_perm=in_perm, out_rows=out_rows)
-        pk["lstm"].append(dict(ih=ih, whh=_bf16(torch.stack(hh, 0)), G=G))
+        # recurrent weights in MFMA-fragment order [dir][u][gate][k-step][lane][8] (cube_bilstm_recurrent)
+        U, KS = G // 64, KH // 32
+        w4 = torch.stack(hh, 0).view(2, U, 4, 16, KS, 4, 8)       # [d][u][g][l15][ks][lq][j]
+        frag = w4.permute(0, 1, 2, 4, 5, 3, 6).reshape(2, U, 4, KS, 64, 8)  # lane = lq*16 + l15
+        pk["lstm"].append(dict(ih=ih, whh=_bf16(frag.contiguous()), G=G))
     # _pre_out reads [h_fwd | h_bwd | lang]  (reference order)
     pk["pre_out"] = pack_linear(sd["_pre_out.linear_layer.weight"], sd["_pre_out.linear_layer.bias"])
     pp_w = pk["pre_out"]["N"]  # width of the pre_parsing buffer (pad columns are tanh(0) = 0)
