@@ -1,0 +1,46 @@
+"""Sentence sharding across the GPUs of one node.
+
+Sentences are independent, so the N>1 path is: one process per GPU, weights replicated, rank r
+runs `Parser.process` on its contiguous block of sentences, no collective on the data path.
+Results depend on which sentences share a batch (the reference pads to the batch maximum and its
+convolutions / LSTM see the pad positions, parser.py:201), so shard boundaries are multiples of
+`batch_size`: every rank then forms exactly the batches the single-process reference would.
+The optional result gather moves five small integer/string columns per word to rank 0.
+"""
+import torch.distributed as dist
+
+
+def shard_bounds(n_sentences, rank, world_size, batch_size):
+    """[lo, hi) of rank's sentences: whole batches, contiguous, in order, balanced to one batch."""
+    n_batches = (n_sentences + batch_size - 1) // batch_size
+    per, extra = divmod(n_batches, world_size)
+    first = rank * per + min(rank, extra)
+    count = per + (1 if rank < extra else 0)
+    return min(first * batch_size, n_sentences), min((first + count) * batch_size, n_sentences)
+
+
+class _Slice:
+    """A view of a Document holding only sentences[lo:hi] (same Sentence objects)."""
+
+    def __init__(self, doc, lo, hi):
+        self.sentences = doc.sentences[lo:hi]
+
+
+def process_sharded(parser, doc, collate, batch_size=4, rank=None, world_size=None, gather=True):
+    """Run `parser.process` on this rank's shard of `doc`; with gather=True rank 0 ends up with
+    every word's head/label/upos/xpos/attrs filled (other ranks: their own shard only)."""
+    rank = dist.get_rank() if rank is None else rank
+    world_size = dist.get_world_size() if world_size is None else world_size
+    lo, hi = shard_bounds(len(doc.sentences), rank, world_size, batch_size)
+    if hi > lo:
+        parser.process(_Slice(doc, lo, hi), collate, batch_size=batch_size, num_workers=0)
+    if gather and world_size > 1:
+        mine = [[(int(w.head), w.label, w.upos, w.xpos, w.attrs) for w in s.words] for s in doc.sentences[lo:hi]]
+        parts = [None] * world_size if rank == 0 else None
+        dist.gather_object((lo, hi, mine), parts, dst=0)
+        if rank == 0:
+            for plo, phi, rows in parts:
+                for s, srow in zip(doc.sentences[plo:phi], rows):
+                    for w, (h, lab, u, x, a) in zip(s.words, srow):
+                        w.head, w.label, w.upos, w.xpos, w.attrs = h, lab, u, x, a
+    return doc

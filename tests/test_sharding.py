@@ -1,0 +1,62 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sentence sharding + result gather, with a
+stand-in parser (the HIP parser needs a GPU; the sharding logic does not)."""
+import os
+import sys
+
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cube_amd import synth
+from cube_amd.sharding import shard_bounds, process_sharded
+
+
+def test_shard_bounds_cover_every_sentence_once_in_whole_batches():
+    for n in (0, 1, 7, 32, 33, 100, 1001):
+        for world in (1, 2, 3, 8):
+            for bs in (1, 4, 32):
+                seen = []
+                for r in range(world):
+                    lo, hi = shard_bounds(n, r, world, bs)
+                    assert lo % bs == 0 or lo == n
+                    seen += list(range(lo, hi))
+                assert seen == list(range(n)), (n, world, bs)
+                sizes = [shard_bounds(n, r, world, bs) for r in range(world)]
+                nb = [-(-(hi - lo) // bs) for lo, hi in sizes]
+                assert max(nb) - min(nb) <= 1
+
+
+class _FakeParser:
+    """fills results as a pure function of the sentence and of its position in its batch."""
+
+    def process(self, doc, collate, batch_size=4, num_workers=0):
+        for start in range(0, len(doc.sentences), batch_size):
+            batch = doc.sentences[start:start + batch_size]
+            lmax = max(len(s.words) for s in batch)
+            for s in batch:
+                for i, w in enumerate(s.words):
+                    w.head = (i + lmax) % (len(s.words) + 1)
+                    w.label, w.upos, w.xpos, w.attrs = "l%d" % lmax, "u%d" % len(w.word), "x", "a%d" % i
+        return doc
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc = synth.make_encodings(n_chars=40, n_words=50, n_upos=6, n_xpos=7, n_attrs=8, n_labels=9, num_langs=2)
+    doc = synth.make_document(enc, [3 + (i * 7) % 11 for i in range(37)], seed=5, ext_word_emb=(4,))
+    process_sharded(_FakeParser(), doc, None, batch_size=4)
+    if rank == 0:
+        with open(out, "w", encoding="utf-8") as f:
+            f.write(str(doc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_run_equals_single_process(tmp_path):
+    out = str(tmp_path / "sharded.conllu")
+    mp.spawn(_worker, args=(2, 29517, out), nprocs=2, join=True)
+    enc = synth.make_encodings(n_chars=40, n_words=50, n_upos=6, n_xpos=7, n_attrs=8, n_labels=9, num_langs=2)
+    doc = synth.make_document(enc, [3 + (i * 7) % 11 for i in range(37)], seed=5, ext_word_emb=(4,))
+    _FakeParser().process(doc, None, batch_size=4)
+    assert open(out, encoding="utf-8").read() == str(doc)
