@@ -16,7 +16,6 @@
 //
 // Epilogues are fused: bias, tanh / relu, the tanh*sigmoid gate with residual accumulation,
 // row scatter (unpack), hi/lo splitting of bf16 outputs.
-#include <stdlib.h>
 #include "common.h"
 #include "../../include/cube_hip.h"
 
@@ -48,7 +47,6 @@ struct GemmParams {
   float* res; int ld_res; int res_mode;
   uint16_t* out1; uint16_t* out1_lo; int ldo1; int col1;
   uint16_t* out2; uint16_t* out2_lo; int ldo2; int col2;
-  int dbg;
 };
 
 __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t idx, float v) {
@@ -180,10 +178,9 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   for (int s = 0; s < nk; ++s) {
     const bool last_tap = (tap == taps - 1);
     if (s + 1 < nk) {
-      if (!(p.dbg & 1)) { ISSUE_B(s + 1, (s + 1) & 1) }
-      if (last_tap && !(p.dbg & 2)) { ISSUE_A(kc + 1, (kc + 1) & 1) }
+      ISSUE_B(s + 1, (s + 1) & 1)
+      if (last_tap) { ISSUE_A(kc + 1, (kc + 1) & 1) }
     }
-    if (p.dbg & 4) { __syncthreads(); if (last_tap) { tap = 0; ++kc; } else { ++tap; } continue; }
     const unsigned char* bbase = smem + B_BASE + (s & 1) * B_BUF;
     // fragment reads run one (k-substep, row tile) unit ahead of the MFMAs that consume them
     int aoff[TM], alo[TM];  // LDS byte offsets of this lane's A fragment (k-substep 0) and hi->lo distance
@@ -351,7 +348,6 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   p.out0 = a->out0; p.out0_lo = (uint16_t*)a->out0_lo; p.ldo0 = a->ldo0; p.col0 = a->col0; p.rowmap = a->rowmap;
   p.res = a->res; p.ld_res = a->ld_res; p.res_mode = a->res_mode;
   p.out1 = (uint16_t*)a->out1; p.out1_lo = (uint16_t*)a->out1_lo; p.ldo1 = a->ldo1; p.col1 = a->col1;
-  { const char* e = getenv("CUBE_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.out2 = (uint16_t*)a->out2; p.out2_lo = (uint16_t*)a->out2_lo; p.ldo2 = a->ldo2; p.col2 = a->col2;
   if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: n_valid=%d > N=%d", p.n_valid, a->N);
   hipStream_t st = (hipStream_t)stream;

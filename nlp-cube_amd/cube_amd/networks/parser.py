@@ -34,12 +34,21 @@ class _Buffers:
         self.device = device
         self.split = split
         self._b = {}
+        self.streams = ()  # side streams whose kernels may still use a buffer when it is replaced
 
     def get(self, name, rows, ld, dtype=torch.bfloat16):
         need = max(rows * ld, 1)
         t = self._b.get(name)
         numel = 0 if t is None else (t.hi.numel() if isinstance(t, hip.Pair) else t.numel())
         if t is None or numel < need:
+            if t is not None:
+                # a larger batch replaces the buffer while kernels of the previous batch may still read
+                # the old one on another stream: tell the allocator, so the memory is not handed out
+                # again before that work is done
+                for plane in ((t.hi, t.lo) if isinstance(t, hip.Pair) else (t,)):
+                    for s in self.streams:
+                        if plane is not None and plane.is_cuda:
+                            plane.record_stream(s)
             if dtype == torch.bfloat16:
                 t = hip.Pair(torch.zeros(need, dtype=dtype, device=self.device),
                              torch.zeros(need, dtype=dtype, device=self.device) if self.split else None)
@@ -67,6 +76,7 @@ class Parser:
         self.training = False
         self.precision = "bf16x3"  # or "bf16"; set before .to(device)
         self._timing = None
+        self._streams = None
 
     # ---- reference-compatible module surface ----------------------------------------------
     def eval(self):
@@ -103,6 +113,7 @@ class Parser:
             self._split = self.precision == "bf16x3"
             self._pk = packing.to_device(self._pk_cpu, device, with_lo=self._split)
             self._buf = _Buffers(device, self._split)
+            self._buf.streams = self._streams or ()
         return self
 
     def _require_gpu(self):
@@ -196,9 +207,9 @@ class Parser:
         if pair.lo is not None:
             pair.lo[:numel].zero_()
 
-    def _encode(self, bt, want_aux=False):
-        """Runs char-CNN, ext MLPs, word-CNN, morphology heads, BiLSTM, pre_parsing and the arc
-        scorer.  Returns a dict of device tensors (views into the workspace)."""
+    def _front(self, bt, slot=0, want_aux=False):
+        """GEMM-heavy first phase: char CNN, ext MLPs, word CNN, morphology heads.  Leaves the LSTM
+        input in xl0_{slot} and the tag logits in slot buffers."""
         self._require_gpu()
         lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
         st = hip.stream_handle()
@@ -207,7 +218,7 @@ class Parser:
         B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
         NW, BT, BL = N * W, B * T, B * L
         ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
-        H = cfg.rnn_size
+        sfx = "_%d" % slot
 
         # ---- character level (WordGram, modules.py:450-484)
         xc0 = buf.get("xc0", NW, lay.xc0_w)
@@ -239,7 +250,7 @@ class Parser:
         gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138)
         xl0_w = p32(wh + lg + P)
-        xl0 = buf.get("xl0", BT, xl0_w)
+        xl0 = buf.get("xl0" + sfx, BT, xl0_w)
         self._zero(xl0, BT * xl0_w)
         ext_h = buf.get("ext_h", BL, pk["ext"][0]["h1"]["N"])
         ld_acc = 8 * ((P + 7) // 8)
@@ -257,7 +268,7 @@ class Parser:
         out = {}
         if want_aux:
             ax = pk["aux"]
-            aux = torch.empty((BT, ax["n_valid"]), dtype=torch.float32, device=self._device)
+            aux = buf.get("aux", BT, ax["n_valid"], torch.float32)[:BT * ax["n_valid"]].view(BT, ax["n_valid"])
             hip.gemm(xw0, lay.xw0_w, BT, ax["K"], ax["W"], ax["N"], ax["bias"], hip.EPI_F32, out0=aux,
                      ldo0=ax["n_valid"], n_valid=ax["n_valid"], a_col=lay.xw0_char, stream=st)
             out["aux"] = aux
@@ -287,31 +298,50 @@ class Parser:
         hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
                  n_valid=q["n_valid"], stream=st)
         n_u = self._sizes["upos"]
-        upos_log = torch.empty((BT, n_u), dtype=torch.float32, device=self._device)
+        upos_log = buf.get("upos_log" + sfx, BT, n_u, torch.float32)[:BT * n_u].view(BT, n_u)
         q = pk["upos"]
         hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=upos_log, ldo0=n_u, n_valid=n_u,
                  stream=st)
-        upos_idx = torch.empty((BT,), dtype=torch.int32, device=self._device)
-        hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, upos_idx.data_ptr(), st), "cube_argmax_rows")
-        emb_idx = upos_idx
+        n_x, n_a = self._sizes["xpos"], self._sizes["attrs"]
+        tag_idx = buf.get("tag_idx" + sfx, 3, BT, torch.int32)[:3 * BT].view(3, BT)  # upos, attrs, xpos
+        hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, tag_idx[0].data_ptr(), st), "cube_argmax_rows")
+        emb_idx = tag_idx[0]
         if "y_upos" in bt:  # gold tags given (training-time behaviour of forward, parser.py:185-188)
             emb_idx = torch.zeros((B, T), dtype=torch.int32, device=self._device)
             emb_idx[:, 1:] = bt["y_upos"]
             emb_idx = emb_idx.view(-1)
+            bt["_gold_idx"] = emb_idx  # lives as long as the batch (the gather below is asynchronous)
         gather(pm, pm_w, wh + lg, 64, pk["upos_emb"], emb_idx, None, BT)
         q = pk["attrs_xpos"]
         n_ax = q["n_valid"]
-        ax_log = torch.empty((BT, n_ax), dtype=torch.float32, device=self._device)
+        ax_log = buf.get("ax_log" + sfx, BT, n_ax, torch.float32)[:BT * n_ax].view(BT, n_ax)
         hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
                  stream=st)
+        hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, 0, n_a, BT, tag_idx[1].data_ptr(), st), "cube_argmax_rows")
+        hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, n_a, n_x, BT, tag_idx[2].data_ptr(), st), "cube_argmax_rows")
+        out.update(xl0=xl0, xl0_w=xl0_w, tag_idx=tag_idx,
+                   upos_logits=upos_log.view(B, T, n_u)[:, 1:, :], ax_logits=ax_log.view(B, T, n_ax)[:, 1:, :],
+                   upos=tag_idx[0].view(B, T)[:, 1:], attrs=tag_idx[1].view(B, T)[:, 1:],
+                   xpos=tag_idx[2].view(B, T)[:, 1:])
+        return out
+
+    def _back(self, bt, fr, slot=0):
+        """Latency-bound second phase: BiLSTM, pre_parsing, arc scorer + softmax.  Adds its outputs
+        to `fr`."""
+        lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
+        st = hip.stream_handle()
+        lo = hip.ptr
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        BT = B * T
+        lg, H = lay.lang, cfg.rnn_size
         # ---- BiLSTM (parser.py:194-202): per layer one projection GEMM + one persistent recurrent kernel
         xl_w = p32(2 * H + lg)
         xla, xlb = buf.get("xla", BT, xl_w), buf.get("xlb", BT, xl_w)
-        gather(xla, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        gather(xlb, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        self._gather(xla, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        self._gather(xlb, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         G2 = 2 * pk["lstm"][0]["G"]
         gx = buf.get("gx", BT, G2, torch.float32)
-        src, src_ld = xl0, xl0_w
+        src, src_ld = fr["xl0"], fr["xl0_w"]
         for l, ly in enumerate(pk["lstm"]):
             ih = ly["ih"]
             dst = xla if l % 2 == 0 else xlb
@@ -334,16 +364,17 @@ class Parser:
         q = pk["head_bilin"]
         u = buf.get("u", BT, Dh)
         hip.gemm(ha, 2 * Dh, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
-        arc_logits = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
-        arc_probs = torch.empty((B, L, T), dtype=torch.float32, device=self._device)
+        arc_logits = buf.get("arc_logits", B * L, T, torch.float32)[:B * L * T].view(B, L, T)
+        arc_probs = buf.get("arc_probs", B * L, T, torch.float32)[:B * L * T].view(B, L, T)
         hip.check(lib.cube_biaffine_arc(u.hi.data_ptr(), lo(u.lo), Dh, ha.hi.data_ptr(), lo(ha.lo), 2 * Dh, Dh, Dh, B, T,
                                         arc_logits.data_ptr(), arc_probs.data_ptr(), st), "cube_biaffine_arc")
-        out.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w,
-                   upos_logits=upos_log.view(B, T, n_u)[:, 1:, :], upos_idx=upos_idx.view(B, T)[:, 1:],
-                   ax_logits=ax_log.view(B, T, n_ax)[:, 1:, :], ax_all=ax_log)
-        return out
+        fr.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w)
+        return fr
 
-    def _label_scores(self, bt, pp, pp_w, heads_dev):
+    def _encode(self, bt, want_aux=False, slot=0):
+        return self._back(bt, self._front(bt, slot, want_aux), slot)
+
+    def _label_scores(self, bt, pp, pp_w, heads_dev, labels_out=None):
         """parser.py:218-233: gather head rows + DeepBiaffine(pairwise=False), fused on device."""
         lib, pk, st = hip.load(), self._pk, hip.stream_handle()
         B, L, T = bt["B"], bt["L"], bt["T"]
@@ -354,14 +385,33 @@ class Parser:
         hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hl, ldo0=2 * Dl,
                  n_valid=2 * Dl, stream=st)
         n_l = self._sizes["labels"]
-        logits = torch.empty((B, L, n_l), dtype=torch.float32, device=self._device)
-        labels = torch.empty((B, L), dtype=torch.int32, device=self._device)
+        logits = self._buf.get("label_logits", B * L, n_l, torch.float32)[:B * L * n_l].view(B, L, n_l)
+        labels = labels_out if labels_out is not None else \
+            self._buf.get("labels", B, L, torch.int32)[:B * L].view(B, L)
         lb = pk["label_bilin"]
         hip.check(lib.cube_label_score(hl.hi.data_ptr(), hip.ptr(hl.lo), 2 * Dl, Dl, Dl, lb["W"].hi.data_ptr(),
                                        hip.ptr(lb["W"].lo), lb["bias"].data_ptr(), n_l, heads_dev.data_ptr(),
                                        bt["lens"].data_ptr(), B, L, logits.data_ptr(), labels.data_ptr(), st),
                   "cube_label_score")
         return logits, labels
+
+    def _decode(self, bt, r, slot=0):
+        """MST heads + labels for an encoded batch; packs [heads, labels, upos, xpos, attrs] as one
+        int32 [5, B, L] device array (`r["packed"]`)."""
+        B, L = bt["B"], bt["L"]
+        packed = self._buf.get("packed_%d" % slot, 5, B * L, torch.int32)[:5 * B * L].view(5, B, L)
+        status = self._buf.get("status_%d" % slot, 1, B, torch.int32)[:B]
+        ws_bytes = hip.load().cube_mst_workspace_bytes(B, L)
+        ws = self._buf.get("mst_ws", 1, (ws_bytes + 7) // 8, torch.int64)
+        hip.check(hip.load().cube_mst_decode(r["arc_probs"].data_ptr(), bt["lens"].data_ptr(), B, L,
+                                             packed[0].data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                             hip.stream_handle()), "cube_mst_decode")
+        label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], packed[0], labels_out=packed[1])
+        packed[2].copy_(r["upos"])
+        packed[3].copy_(r["xpos"])
+        packed[4].copy_(r["attrs"])
+        r.update(heads=packed[0], labels=labels, status=status, label_logits=label_logits, packed=packed, bt=bt)
+        return r
 
     # ---- reference API ---------------------------------------------------------------------
     def forward(self, X):
@@ -394,7 +444,8 @@ class Parser:
         pp.hi[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = src.hi
         if self._split:
             pp.lo[:B * T * pp_w].view(B, T, pp_w)[:, :, :labels.shape[-1]] = src.lo
-        logits, _ = self._label_scores(bt, pp, pp_w, torch.from_numpy(hp).to(self._device))
+        bt["_heads"] = torch.from_numpy(hp).to(self._device)  # kept with the batch: the kernel is asynchronous
+        logits, _ = self._label_scores(bt, pp, pp_w, bt["_heads"])
         return logits
 
     def decode_batch(self, X):
@@ -402,45 +453,93 @@ class Parser:
         return self.decode_batch_prepared(self._prepare(X))
 
     def decode_batch_prepared(self, bt):
-        r = self._encode(bt)
-        heads, status = self._decoder.decode_device(r["arc_probs"], bt["lens"])
-        label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], heads)
-        lib, st = hip.load(), hip.stream_handle()
-        B, L, T = bt["B"], bt["L"], bt["T"]
-        n_x, n_a = self._sizes["xpos"], self._sizes["attrs"]
-        n_ax = n_a + n_x
-        ax_idx = torch.empty((2, B * T), dtype=torch.int32, device=self._device)
-        hip.check(lib.cube_argmax_rows(r["ax_all"].data_ptr(), n_ax, 0, n_a, B * T, ax_idx[0].data_ptr(), st), "argmax")
-        hip.check(lib.cube_argmax_rows(r["ax_all"].data_ptr(), n_ax, n_a, n_x, B * T, ax_idx[1].data_ptr(), st), "argmax")
-        r.update(heads=heads, status=status, label_logits=label_logits, labels=labels,
-                 upos=r["upos_idx"], attrs=ax_idx[0].view(B, T)[:, 1:], xpos=ax_idx[1].view(B, T)[:, 1:], bt=bt)
-        return r
+        """Single-stream, in-order execution on the current stream (tests / forward-style use);
+        returns device tensors (views into the workspace, valid until the next batch)."""
+        return self._decode(bt, self._encode(bt))
+
+    # ---- pipelined execution: GEMM-heavy phase of batch i+1 overlaps the latency-bound phase of i ----
+    def submit(self, bt):
+        """Enqueue one prepared batch.  Phase 1 (char/word CNNs, tag heads: fills all CUs) runs on
+        one HIP stream, phase 2 (persistent BiLSTM, arc scorer, MST, labels: few workgroups, serial
+        steps) on a second one, so phase 2 of a batch hides under phase 1 of the next.  Returns a
+        ticket for `collect`.  At most two batches may be in flight."""
+        self._require_gpu()
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
+            self._slot_free = [None, None]
+            self._host_res = [None, None]
+            self._n_submitted = 0
+            self._buf.streams = self._streams
+        slot = self._n_submitted % 2
+        self._n_submitted += 1
+        s1, s2 = self._streams
+        cur = torch.cuda.current_stream()
+        B, L = bt["B"], bt["L"]
+        with torch.cuda.stream(s1):
+            s1.wait_stream(cur)  # inputs uploaded on the caller's stream
+            if self._slot_free[slot] is not None:
+                s1.wait_event(self._slot_free[slot])
+            fr = self._front(bt, slot)
+            ev_front = torch.cuda.Event()
+            ev_front.record(s1)
+        with torch.cuda.stream(s2):
+            s2.wait_event(ev_front)
+            r = self._decode(bt, self._back(bt, fr, slot), slot)
+            n = 5 * B * L
+            host = self._host_res[slot]
+            if host is None or host.numel() < n + B:
+                host = torch.empty(n + B, dtype=torch.int32, pin_memory=True)
+                self._host_res[slot] = host
+            host[:n].view(5, B, L).copy_(r["packed"], non_blocking=True)
+            host[n:n + B].copy_(r["status"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(s2)
+            self._slot_free[slot] = done
+        # the ticket keeps the batch's device inputs alive until `collect`: they were allocated on the
+        # caller's stream, and freeing them earlier would let the next upload reuse their memory
+        # while the kernels of this batch (on s1 / s2) still read it
+        return dict(slot=slot, done=done, B=B, L=L, bt=bt)
+
+    def collect(self, ticket):
+        """Wait for a submitted batch: -> (int32 [5, B, L] = heads, labels, upos, xpos, attrs; status [B])."""
+        ticket["done"].synchronize()
+        ticket.pop("bt", None)
+        B, L = ticket["B"], ticket["L"]
+        host = self._host_res[ticket["slot"]]
+        n = 5 * B * L
+        return host[:n].view(5, B, L).numpy().copy(), host[n:n + B].numpy().copy()
+
+    def _write_back(self, batch, start, res, status):
+        """parser.py:432-446: ids -> strings, into the Document."""
+        if (status != 0).any():
+            raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
+                                 % (start + np.where(status != 0)[0]).tolist())
+        enc = self._encodings
+        heads = res[0].astype(np.int64)
+        for b, s in enumerate(batch):
+            for i, w in enumerate(s.words):
+                w.head = heads[b, i]
+                w.label = enc.labels[res[1, b, i]]
+                w.upos = enc.upos_list[res[2, b, i]]
+                w.xpos = enc.xpos_list[res[3, b, i]]
+                w.attrs = enc.attrs_list[res[4, b, i]]
 
     def process(self, doc, collate, batch_size=4, num_workers=4):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
-        head/label/upos/xpos/attrs of every word of `doc` and returns it."""
+        head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
+        two deep (featurisation and write-back of neighbours overlap the GPU)."""
         self.eval()
         self._require_gpu()
-        enc = self._encodings
         sents = doc.sentences
+        pending = None
         for start in range(0, len(sents), batch_size):
             batch = sents[start:start + batch_size]
             X = collate.collate_fn(batch)
             X.pop("y_upos", None)
-            r = self.decode_batch(X)
-            B, L = r["bt"]["B"], r["bt"]["L"]
-            res = torch.stack([r["heads"], r["labels"], r["upos"].contiguous(), r["xpos"].contiguous(),
-                               r["attrs"].contiguous()]).cpu().numpy()
-            status = r["status"].cpu().numpy()
-            if (status != 0).any():
-                raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
-                                     % (start + np.where(status != 0)[0]).tolist())
-            heads = res[0].astype(np.int64)
-            for b, s in enumerate(batch):
-                for i, w in enumerate(s.words):
-                    w.head = heads[b, i]
-                    w.label = enc.labels[res[1, b, i]]
-                    w.upos = enc.upos_list[res[2, b, i]]
-                    w.xpos = enc.xpos_list[res[3, b, i]]
-                    w.attrs = enc.attrs_list[res[4, b, i]]
+            ticket = self.submit(self._prepare(X))
+            if pending is not None:
+                self._write_back(pending[0], pending[1], *self.collect(pending[2]))
+            pending = (batch, start, ticket)
+        if pending is not None:
+            self._write_back(pending[0], pending[1], *self.collect(pending[2]))
         return doc

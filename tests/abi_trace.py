@@ -1,0 +1,221 @@
+"""Dry-run checker of the host side of the C ABI (CPU only, no kernels run).
+
+`TraceLib` stands in for libcubehip.so: every entry point records its arguments and checks that
+each pointer the host hands over lies inside a live tensor and covers every byte the kernel
+behind that entry point reads or writes (extents restated from include/cube_hip.h).  Index arrays
+are host memory in a dry run, so gathers are checked with their real row numbers.  This is the
+"operand shapes match what the kernel and its grid assume" check, run before anything goes to a
+GPU.  It computes nothing: outputs stay zero, so it says nothing about values.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from cube_amd import hip
+
+
+class ExtentError(AssertionError):
+    pass
+
+
+def _walk(obj, out):
+    if isinstance(obj, hip.Pair):
+        _walk(obj.hi, out)
+        _walk(obj.lo, out)
+    elif isinstance(obj, torch.Tensor):
+        st = obj.untyped_storage()
+        out.append((st.data_ptr(), st.nbytes()))
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _walk(v, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _walk(v, out)
+
+
+class TraceLib:
+    """Fake library object: same attribute names as the ctypes library in cube_amd.hip."""
+
+    def __init__(self, roots):
+        self.roots = roots          # callables returning objects whose tensors are "live"
+        self.calls = []
+        self.extra = []             # tensors registered by the test (inputs it owns)
+
+    # ---- registry --------------------------------------------------------------------------
+    def _regions(self):
+        out = []
+        for r in self.roots:
+            _walk(r(), out)
+        _walk(self.extra, out)
+        return out
+
+    def _need(self, what, ptr, nbytes, align=1):
+        if ptr is None or nbytes <= 0:
+            return
+        ptr = int(ptr)
+        if ptr % align:
+            raise ExtentError("%s: pointer not %d-byte aligned" % (what, align))
+        for base, size in self._regions():
+            if base <= ptr < base + size:
+                if ptr + nbytes > base + size:
+                    raise ExtentError("%s: needs %d bytes, only %d left in its tensor" % (what, nbytes, base + size - ptr))
+                return
+        raise ExtentError("%s: pointer is not inside any live tensor (freed temporary?)" % what)
+
+    def _ints(self, what, ptr, n):
+        self._need(what, ptr, 4 * n, 4)
+        return np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(int(ptr))).copy()
+
+    # ---- entry points ----------------------------------------------------------------------
+    def cube_last_error(self):
+        return b""
+
+    def cube_abi_version(self):
+        return 1
+
+    def cube_gemm_bf16(self, ref, stream):
+        a = ref._obj
+        self.calls.append(("gemm", a.epilogue, a.M, a.N, a.Kc, a.taps))
+        M, N, Kc, taps = a.M, a.N, a.Kc, a.taps
+        assert Kc % 32 == 0 and N % 128 == 0 and a.lda >= Kc and a.lda % 8 == 0
+        assert taps == 1 or (a.seq_len > 0 and M % a.seq_len == 0)
+        for nm, p in (("A", a.A), ("A_lo", a.A_lo)):
+            self._need("gemm " + nm, p, 2 * ((M - 1) * a.lda + Kc), 16)
+        for nm, p in (("W", a.W), ("W_lo", a.W_lo)):
+            self._need("gemm " + nm, p, 2 * N * taps * Kc, 16)
+        gate = a.epilogue == hip.EPI_GATE
+        nv = a.n_valid if a.n_valid > 0 else (N // 2 if gate else N)
+        self._need("gemm bias", a.bias, 4 * (N if gate else nv), 4)
+        rows = M
+        if a.rowmap:
+            rm = self._ints("gemm rowmap", a.rowmap, M)
+            rows = int(rm.max()) + 1
+        esz = 4 if a.epilogue == hip.EPI_F32 else 2
+        assert a.ldo0 >= a.col0 + nv or not a.out0
+        for nm, p in (("out0", a.out0), ("out0_lo", a.out0_lo)):
+            self._need("gemm " + nm, p, esz * ((rows - 1) * a.ldo0 + a.col0 + nv), esz)
+        if gate:
+            self._need("gemm res", a.res, 4 * ((M - 1) * a.ld_res + nv), 4)
+            for nm, p, ld, c in (("out1", a.out1, a.ldo1, a.col1), ("out1_lo", a.out1_lo, a.ldo1, a.col1),
+                                 ("out2", a.out2, a.ldo2, a.col2), ("out2_lo", a.out2_lo, a.ldo2, a.col2)):
+                self._need("gemm " + nm, p, 2 * ((M - 1) * ld + c + nv), 2)
+        return 0
+
+    def cube_gather_rows(self, dst, ld_dst, col0, width, table, ld_table, idx, dst_rows, n, stream):
+        self.calls.append(("gather", n, width))
+        if n <= 0 or width <= 0:
+            return 0
+        assert col0 >= 0 and col0 + width <= ld_dst and width <= ld_table
+        src_max = int(self._ints("gather idx", idx, n).max()) if idx else 0
+        assert src_max >= 0
+        if dst_rows:
+            dr = self._ints("gather dst_rows", dst_rows, n)
+            dmax = int(dr.max())
+        else:
+            dmax = n - 1
+        self._need("gather table", table, 2 * (src_max * ld_table + width), 2)
+        self._need("gather dst", dst, 2 * (dmax * ld_dst + col0 + width), 2)
+        return 0
+
+    def cube_masked_mean(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, stream):
+        self.calls.append(("masked_mean", n_layers, N, W, C))
+        assert 0 < n_layers <= 8 and C <= ld_x and C <= ld_out
+        for k in range(n_layers):
+            self._need("masked_mean x_hi[%d]" % k, x_hi[k], 2 * ((N * W - 1) * ld_x + C), 2)
+            if x_lo is not None:
+                self._need("masked_mean x_lo[%d]" % k, x_lo[k], 2 * ((N * W - 1) * ld_x + C), 2)
+        self._need("masked_mean len", length, 4 * N, 4)
+        for nm, p in (("out", out), ("out_lo", out_lo)):
+            self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
+        return 0
+
+    def cube_ext_finish(self, acc, ld_acc, B, L, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):
+        self.calls.append(("ext_finish", B, L, P))
+        assert P <= ld_acc and col_a + P <= ld_a and col_b + P <= ld_b
+        self._need("ext_finish acc", acc, 4 * ((B * L - 1) * ld_acc + P), 4)
+        last = B * (L + 1) - 1
+        for nm, p, ld, c in (("a", da, ld_a, col_a), ("a_lo", da_lo, ld_a, col_a), ("b", db, ld_b, col_b),
+                             ("b_lo", db_lo, ld_b, col_b)):
+            self._need("ext_finish dst_" + nm, p, 2 * (last * ld + c + P), 2)
+        return 0
+
+    def cube_argmax_rows(self, x, ld, col0, n, M, out, stream):
+        self.calls.append(("argmax", M, n))
+        assert n > 0 and col0 >= 0 and col0 + n <= ld
+        self._need("argmax x", x, 4 * ((M - 1) * ld + col0 + n), 4)
+        self._need("argmax out", out, 4 * M, 4)
+        return 0
+
+    def cube_bilstm_recurrent(self, gx, whh, whh_lo, B, T, H, out, out_lo, ld_out, col0, stream):
+        self.calls.append(("bilstm", B, T, H))
+        U, KS = (H + 15) // 16, (H + 31) // 32
+        assert col0 + 2 * H <= ld_out and (whh_lo is None) == (out_lo is None)
+        self._need("bilstm gx", gx, 4 * B * T * 2 * U * 64, 4)
+        for nm, p in (("whh", whh), ("whh_lo", whh_lo)):
+            self._need("bilstm " + nm, p, 2 * 2 * U * 4 * KS * 512, 16)
+        for nm, p in (("out", out), ("out_lo", out_lo)):
+            self._need("bilstm " + nm, p, 2 * ((B * T - 1) * ld_out + col0 + 2 * H), 2)
+        return 0
+
+    def cube_biaffine_arc(self, u, u_lo, ld_u, h2, h2_lo, ld_h2, col_h2, D, B, T, logits, probs, stream):
+        self.calls.append(("biaffine", B, T, D))
+        assert D % 16 == 0 and D <= ld_u and col_h2 + D <= ld_h2 and ld_u % 8 == 0 and ld_h2 % 8 == 0 and col_h2 % 8 == 0
+        for nm, p in (("u", u), ("u_lo", u_lo)):
+            self._need("biaffine " + nm, p, 2 * ((B * T - 1) * ld_u + D), 16)
+        for nm, p in (("h2", h2), ("h2_lo", h2_lo)):
+            self._need("biaffine " + nm, p, 2 * ((B * T - 1) * ld_h2 + col_h2 + D), 16)
+        for nm, p in (("logits", logits), ("probs", probs)):
+            self._need("biaffine " + nm, p, 4 * B * (T - 1) * T, 4)
+        return 0
+
+    @staticmethod
+    def cube_mst_workspace_bytes(B, L):
+        a16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+        nt = B * L
+        return 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * (L + 1))
+
+    def cube_mst_decode(self, probs, lens, B, L, heads, status, ws, ws_bytes, stream):
+        self.calls.append(("mst", B, L))
+        assert L + 1 <= 130 and ws_bytes >= self.cube_mst_workspace_bytes(B, L)
+        self._need("mst probs", probs, 4 * B * L * (L + 1), 4)
+        self._need("mst lens", lens, 4 * B, 4)
+        self._need("mst heads", heads, 4 * B * L, 4)
+        self._need("mst status", status, 4 * B, 4)
+        self._need("mst workspace", ws, ws_bytes, 16)
+        return 0
+
+    def cube_label_score(self, hl, hl_lo, ld_hl, col_x2, D, wl, wl_lo, bias, n_labels, heads, lens, B, L, logits,
+                         labels, stream):
+        self.calls.append(("label", B, L, D, n_labels))
+        assert D % 32 == 0 and D <= col_x2 and col_x2 + D <= ld_hl and ld_hl % 8 == 0 and col_x2 % 8 == 0
+        T = L + 1
+        for nm, p in (("hl", hl), ("hl_lo", hl_lo)):
+            self._need("label " + nm, p, 2 * ((B * T - 1) * ld_hl + col_x2 + D), 16)
+        for nm, p in (("wl", wl), ("wl_lo", wl_lo)):
+            self._need("label " + nm, p, 2 * n_labels * D * D, 16)
+        self._need("label bias", bias, 4 * n_labels, 4)
+        h = self._ints("label heads", heads, B * L)
+        assert h.min() >= 0 and h.max() <= L
+        self._need("label lens", lens, 4 * B, 4)
+        self._need("label logits", logits, 4 * B * L * n_labels, 4)
+        self._need("label labels", labels, 4 * B * L, 4)
+        return 0
+
+
+def dry_parser(case_cfg, enc, sd, ext, precision, monkeypatch):
+    """A Parser whose device is the host and whose library is a TraceLib."""
+    from cube_amd.networks import packing
+    from cube_amd.networks import parser as parser_mod
+    p = parser_mod.Parser(case_cfg, enc, ext_word_emb=list(ext))
+    p.precision = precision
+    p.load_state_dict(sd)
+    p._device = torch.device("cpu")
+    p._split = precision == "bf16x3"
+    p._pk = packing.to_device(p._pk_cpu, "cpu", with_lo=p._split)
+    p._buf = parser_mod._Buffers("cpu", p._split)
+    lib = TraceLib([lambda: p._pk, lambda: p._buf._b, lambda: getattr(p, "_last_bt", None)])
+    monkeypatch.setattr(hip, "load", lambda: lib)
+    monkeypatch.setattr(hip, "stream_handle", lambda: 0)
+    monkeypatch.setattr(p, "_require_gpu", lambda: None)
+    return p, lib

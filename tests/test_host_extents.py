@@ -1,0 +1,74 @@
+"""Host logic of the parser path, dry-run on the CPU: every pointer / leading dimension the
+Python host passes through the C ABI must cover what the kernel behind it touches
+(tests/abi_trace.py).  No compute, no GPU."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.abi_trace import dry_parser, ExtentError
+
+
+def _batch(case, enc, key):
+    from cube_amd.networks.utils import MorphoCollate
+    doc = cases.document(case, enc, key)
+    X = MorphoCollate(enc).collate_fn(doc.sentences)
+    return doc, X
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case,keys", [(cases.TINY, ("single", "equal", "ragged", "g6", "single")),
+                                       (cases.FULL, ("ragged", "full_8x32", "full_2x128", "single"))])
+def test_decode_batch_extents(monkeypatch, case, keys, precision):
+    """Batches of growing and shrinking shapes through one Parser (the grow-only workspace is
+    re-used): all ~60 ABI calls per batch stay inside their tensors."""
+    cfg, enc, sd = cases.parser_model(case)
+    p, lib = dry_parser(cfg, enc, sd, case["ext"], precision, monkeypatch)
+    for key in keys:
+        doc, X = _batch(case, enc, key)
+        X.pop("y_upos")
+        bt = p._prepare(X)
+        lib.extra = [bt]
+        n0 = len(lib.calls)
+        r = p.decode_batch_prepared(bt)
+        names = [c[0] for c in lib.calls[n0:]]
+        assert names.count("mst") == 1 and names.count("label") == 1 and names.count("biaffine") == 1
+        assert names.count("bilstm") == cfg.rnn_layers
+        B, L = bt["B"], bt["L"]
+        assert tuple(r["packed"].shape) == (5, B, L) and tuple(r["arc_logits"].shape) == (B, L, L + 1)
+        assert tuple(r["upos"].shape) == (B, L) and tuple(r["status"].shape) == (B,)
+
+
+def test_forward_and_get_labels_extents(monkeypatch):
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p, lib = dry_parser(cfg, enc, sd, case["ext"], "bf16x3", monkeypatch)
+    doc, X = _batch(case, enc, "ragged")
+    gold = X["y_upos"]
+    outs = p.forward(X)  # with y_upos: gold tags feed the upos embedding (parser.py:185-188)
+    assert len(outs) == 8
+    B, L = X["x_sent"].shape
+    assert tuple(outs[0].shape) == (B, L, L + 1) and tuple(outs[2].shape)[:2] == (B, L)
+    assert gold.shape == (B, L)
+    heads = [np.zeros(len(s.words), dtype=np.int64) for s in doc.sentences]
+    lab = p._get_labels(outs[1], heads)
+    assert tuple(lab.shape)[:2] == (B, L)
+
+
+def test_tracer_catches_a_short_buffer(monkeypatch):
+    """The checker itself: shrinking one workspace buffer under the host's feet must be caught."""
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p, lib = dry_parser(cfg, enc, sd, case["ext"], "bf16x3", monkeypatch)
+    doc, X = _batch(case, enc, "equal")
+    X.pop("y_upos")
+    bt = p._prepare(X)
+    lib.extra = [bt]
+    p.decode_batch_prepared(bt)
+    real_get = p._buf.get
+
+    def short_get(name, rows, ld, dtype=torch.bfloat16):
+        return real_get(name, rows, ld, dtype) if name != "gx" else torch.zeros(8, dtype=dtype)
+    monkeypatch.setattr(p._buf, "get", short_get)
+    with pytest.raises(ExtentError):
+        p.decode_batch_prepared(bt)
