@@ -14,7 +14,7 @@
  *   cube_gather_rows        nn.Embedding lookups + torch.cat (modules.py:451-457;
  *                           parser.py:140-154), unpack() (utils.py:17-32)
  *   cube_masked_mean        WordGram masked mean (modules.py:480-483)
- *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197)
+ *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197; tagger.py:118-119)
  *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
  *   cube_bilstm_recurrent   torch.lstm recurrence, 1 layer, both directions (parser.py:201)
  *   cube_biaffine_arc       PairwiseBilinear bmm + torch.softmax (modules.py:518-533;
@@ -90,8 +90,10 @@ int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const flo
                      void* out, void* out_lo, int ld_out, void* stream);
 
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
- * bf16(e) -> dst_a[(b*(L+1) + i + 1), col_a..+P) and dst_b[same row, col_b..+P)            */
-int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K,
+ * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);
+ * root = 1: the destination keeps a root row in front of every sentence (parser.py:195-197),
+ * root = 0: it does not (tagger.py:111-119).  dst_b may be NULL.                            */
+int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K,
                     void* dst_a, void* dst_a_lo, int ld_a, int col_a,
                     void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream);
 

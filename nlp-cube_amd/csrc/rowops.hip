@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 1; }
+extern "C" int cube_abi_version(void) { return 2; }
 
 namespace {
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_
   }
 }
 
-__global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int P, float K,
+__global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K,
                                                          uint16_t* da, uint16_t* da_lo, int ld_a, int col_a,
                                                          uint16_t* db, uint16_t* db_lo, int ld_b, int col_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int l
   const float e = tanhf_(acc[(size_t)r * ld_acc + c] / K);
   uint16_t v, vl;
   split_bf16(e, v, vl);
-  const size_t orow = (size_t)b * (L + 1) + i + 1;
+  const size_t orow = (size_t)b * (L + root) + i + root;
   if (da) da[orow * ld_a + col_a + c] = v;
   if (db) db[orow * ld_b + col_b + c] = v;
   if (da_lo) da_lo[orow * ld_a + col_a + c] = vl;
@@ -158,14 +158,14 @@ extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo
   return CUBE_OK;
 }
 
-extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int P, int K, void* dst_a, void* dst_a_lo,
+extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, void* dst_a, void* dst_a_lo,
                                int ld_a, int col_a, void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream) {
   if (B <= 0 || L <= 0 || P <= 0) return CUBE_OK;
-  if (!acc || K <= 0 || P > ld_acc) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
+  if (!acc || K <= 0 || P > ld_acc || (root != 0 && root != 1)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
   if ((dst_a && col_a + P > ld_a) || (dst_b && col_b + P > ld_b)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad columns");
   const int total = B * L * P;
   hipLaunchKernelGGL(ext_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, ld_acc, B, L,
-                     P, (float)K, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
+                     root, P, (float)K, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
                      (uint16_t*)dst_b_lo, ld_b, col_b);
   CUBE_CHECK_LAUNCH("cube_ext_finish");
   return CUBE_OK;

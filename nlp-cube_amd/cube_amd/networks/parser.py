@@ -58,7 +58,13 @@ class _Buffers:
         return t
 
 
-class Parser:
+class _HipNet:
+    """What Parser and Tagger share: weight packing / upload, batch preparation, the character-level
+    and word-level gated CNN trunk.  `_root` = 1 when every sentence gets a learned root row in
+    front (parser), 0 otherwise (tagger)."""
+    _root = 1
+    _pack = staticmethod(packing.pack_parser)
+
     def __init__(self, config, encodings, language_codes=None, ext_word_emb=0):
         self._config = config
         self._encodings = encodings
@@ -88,7 +94,7 @@ class Parser:
         sizes = dict(upos=len(enc.upos2int), xpos=len(enc.xpos2int), attrs=len(enc.attrs2int),
                      labels=len(enc.label2int))
         self._sizes = sizes
-        self._pk_cpu, self._lay = packing.pack_parser(state_dict, self._config, sizes, self._ext_word_emb)
+        self._pk_cpu, self._lay = self._pack(state_dict, self._config, sizes, self._ext_word_emb)
         self._pk = None
         if self._device.type == "cuda":
             self.to(self._device)
@@ -118,8 +124,8 @@ class Parser:
 
     def _require_gpu(self):
         if self._pk is None or self._device.type != "cuda":
-            raise hip.CubeHipError("cube_amd Parser runs only on an MI355X: load weights and call .to('cuda:N') "
-                                   "(there is no CPU fallback)")
+            raise hip.CubeHipError("cube_amd %s runs only on an MI355X: load weights and call .to('cuda:N') "
+                                   "(there is no CPU fallback)" % type(self).__name__)
 
     # ---- live kernel timing (bench.py roofline): HIP events on the launch stream ----------
     def start_kernel_timing(self, tag):
@@ -160,16 +166,17 @@ class Parser:
         x_word = X["x_word"].cpu().numpy()
         B, L = x_sent.shape
         N, W = x_word.shape
-        T = L + 1
+        root = self._root
+        T = L + root
         lang_sent = X["x_lang_sent"].cpu().numpy()
         sb = np.repeat(np.arange(B), sl)
         si = np.arange(N) - np.repeat(np.cumsum(sl) - sl, sl)
         word_idx = np.zeros((B, T), dtype=np.int32)
-        word_idx[:, 1:] = x_sent
+        word_idx[:, root:] = x_sent
         parts = [
             x_word.reshape(-1), X["x_word_case"].cpu().numpy().reshape(-1),
             np.repeat(X["x_lang_word"].cpu().numpy(), W), X["x_word_len"].cpu().numpy(),
-            sb * T + si + 1, word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
+            sb * T + si + root, word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
         ]
         sizes = [p.size for p in parts]
         offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
@@ -207,9 +214,14 @@ class Parser:
         if pair.lo is not None:
             pair.lo[:numel].zero_()
 
-    def _front(self, bt, slot=0, want_aux=False):
-        """GEMM-heavy first phase: char CNN, ext MLPs, word CNN, morphology heads.  Leaves the LSTM
-        input in xl0_{slot} and the tag logits in slot buffers."""
+    def _trunk(self, bt, final, final_w, lang_dsts, tap=None, tap_w=0, ext_b=None, ext_b_w=0, ext_b_col=0,
+               want_aux=False):
+        """Character CNN (WordGram, modules.py:450-484), external-embedding MLPs, word-level input
+        assembly and the word-level gated CNN (parser.py:130-176 / tagger.py:102-148).
+        final: Pair [B*T, final_w] that receives x+res of the last layer in columns [0, word_half);
+        tap: Pair that receives x+res after layer `aux_softmax_location` (parser only);
+        lang_dsts: (Pair, ld) buffers whose columns [word_half, word_half+lang) get the language
+        embedding; ext_b: optional second destination of the projected external embeddings."""
         self._require_gpu()
         lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
         st = hip.stream_handle()
@@ -218,9 +230,8 @@ class Parser:
         B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
         NW, BT, BL = N * W, B * T, B * L
         ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
-        sfx = "_%d" % slot
 
-        # ---- character level (WordGram, modules.py:450-484)
+        # ---- character level
         xc0 = buf.get("xc0", NW, lay.xc0_w)
         gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, NW)
         gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, NW)
@@ -240,7 +251,7 @@ class Parser:
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
         hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w, stream=st)
-        # ---- word level input XW0 = [word | char | lang | ext], root row = _r_emb
+        # ---- word level input XW0 = [word | char | lang | ext] (+ root row = _r_emb for the parser)
         xw0 = buf.get("xw0", BT, lay.xw0_w)
         self._zero(xw0, BT * lay.xw0_w)
         gather(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT)
@@ -248,10 +259,7 @@ class Parser:
         hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
                  col0=lay.xw0_char, n_valid=ch, rowmap=bt["rowmap_word"], stream=st)
         gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138)
-        xl0_w = p32(wh + lg + P)
-        xl0 = buf.get("xl0" + sfx, BT, xl0_w)
-        self._zero(xl0, BT * xl0_w)
+        # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138, tagger.py:111-119)
         ext_h = buf.get("ext_h", BL, pk["ext"][0]["h1"]["N"])
         ld_acc = 8 * ((P + 7) // 8)
         ext_acc = buf.get("ext_acc", BL, ld_acc, torch.float32)
@@ -261,10 +269,12 @@ class Parser:
                      out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
             hip.gemm(ext_h, h1["N"], BL, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
                      n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
-        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, P, len(pk["ext"]), xw0.hi.data_ptr(),
-                                      lo(xw0.lo), lay.xw0_w, lay.xw0_ext, xl0.hi.data_ptr(), lo(xl0.lo), xl0_w,
-                                      wh + lg, st), "cube_ext_finish")
-        gather(xw0, lay.xw0_w, 0, lay.xw0_w, pk["r_emb"], None, bt["root_rows"], B)
+        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, self._root, P, len(pk["ext"]), xw0.hi.data_ptr(),
+                                      lo(xw0.lo), lay.xw0_w, lay.xw0_ext,
+                                      None if ext_b is None else ext_b.hi.data_ptr(),
+                                      None if ext_b is None else lo(ext_b.lo), ext_b_w, ext_b_col, st), "cube_ext_finish")
+        if self._root:
+            gather(xw0, lay.xw0_w, 0, lay.xw0_w, pk["r_emb"], None, bt["root_rows"], B)
         out = {}
         if want_aux:
             ax = pk["aux"]
@@ -272,57 +282,90 @@ class Parser:
             hip.gemm(xw0, lay.xw0_w, BT, ax["K"], ax["W"], ax["N"], ax["bias"], hip.EPI_F32, out0=aux,
                      ldo0=ax["n_valid"], n_valid=ax["n_valid"], a_col=lay.xw0_char, stream=st)
             out["aux"] = aux
-        # ---- word-level gated CNN (parser.py:157-176)
+        # ---- word-level gated CNN
         xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
         resw = buf.get("resw", BT, wh, torch.float32)
-        xm_w = p32(wh + lg)
-        xm = buf.get("xm", BT, xm_w)
-        for dstb, ldb in ((xwa, lay.xw_w), (xwb, lay.xw_w), (xm, xm_w), (xl0, xl0_w)):
+        for dstb, ldb in [(xwa, lay.xw_w), (xwb, lay.xw_w)] + list(lang_dsts):
             gather(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         nword = len(pk["word_convs"])
         src, src_ld = xw0, lay.xw0_w
         for l, cv in enumerate(pk["word_convs"]):
             last = l == nword - 1
             dst = None if last else (xwa if l % 2 == 0 else xwb)
-            aux_here = (l + 1 == cfg.aux_softmax_location)
-            o1, o2 = (xm if aux_here else None), (xl0 if last else None)
+            aux_here = tap is not None and (l + 1 == cfg.aux_softmax_location)
+            o1, o2 = (tap if aux_here else None), (final if last else None)
             hip.gemm(src, src_ld, BT, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
                      col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh,
-                     res_mode=0 if l == 0 else 1, out1=o1, ldo1=xm_w, col1=0, out2=o2, ldo2=xl0_w, col2=0, stream=st)
+                     res_mode=0 if l == 0 else 1, out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0, stream=st)
             src, src_ld = dst, lay.xw_w
-        # ---- morphology heads (parser.py:178-192); PM = [pre_morpho | lang | upos_emb]
-        pm_w = p32(wh + lg + 64)
-        pm = buf.get("pm", BT, pm_w)
-        gather(pm, pm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        q = pk["pre_morpho"]
-        hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
-                 n_valid=q["n_valid"], stream=st)
-        n_u = self._sizes["upos"]
+        return out
+
+    def _tag_heads(self, bt, slot, x, x_w, upos_key, emb_col):
+        """UPOS logits -> arg-max (or gold tags) -> UPOS embedding into columns [emb_col, emb_col+64)
+        of `x` -> ATTRS | XPOS logits; arg-max of all three (parser.py:180-192, tagger.py:153-161)."""
+        lib, pk, buf, st = hip.load(), self._pk, self._buf, hip.stream_handle()
+        B, T = bt["B"], bt["T"]
+        BT, root = B * T, self._root
+        sfx = "_%d" % slot
+        n_u, n_x, n_a = self._sizes["upos"], self._sizes["xpos"], self._sizes["attrs"]
         upos_log = buf.get("upos_log" + sfx, BT, n_u, torch.float32)[:BT * n_u].view(BT, n_u)
-        q = pk["upos"]
-        hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=upos_log, ldo0=n_u, n_valid=n_u,
+        q = pk[upos_key]
+        hip.gemm(x, x_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=upos_log, ldo0=n_u, n_valid=n_u,
                  stream=st)
-        n_x, n_a = self._sizes["xpos"], self._sizes["attrs"]
         tag_idx = buf.get("tag_idx" + sfx, 3, BT, torch.int32)[:3 * BT].view(3, BT)  # upos, attrs, xpos
         hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, tag_idx[0].data_ptr(), st), "cube_argmax_rows")
         emb_idx = tag_idx[0]
         if "y_upos" in bt:  # gold tags given (training-time behaviour of forward, parser.py:185-188)
             emb_idx = torch.zeros((B, T), dtype=torch.int32, device=self._device)
-            emb_idx[:, 1:] = bt["y_upos"]
+            emb_idx[:, root:] = bt["y_upos"]
             emb_idx = emb_idx.view(-1)
             bt["_gold_idx"] = emb_idx  # lives as long as the batch (the gather below is asynchronous)
-        gather(pm, pm_w, wh + lg, 64, pk["upos_emb"], emb_idx, None, BT)
+        self._gather(x, x_w, emb_col, 64, pk["upos_emb"], emb_idx, None, BT)
         q = pk["attrs_xpos"]
         n_ax = q["n_valid"]
         ax_log = buf.get("ax_log" + sfx, BT, n_ax, torch.float32)[:BT * n_ax].view(BT, n_ax)
-        hip.gemm(pm, pm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
+        hip.gemm(x, x_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
                  stream=st)
         hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, 0, n_a, BT, tag_idx[1].data_ptr(), st), "cube_argmax_rows")
         hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, n_a, n_x, BT, tag_idx[2].data_ptr(), st), "cube_argmax_rows")
-        out.update(xl0=xl0, xl0_w=xl0_w, tag_idx=tag_idx,
-                   upos_logits=upos_log.view(B, T, n_u)[:, 1:, :], ax_logits=ax_log.view(B, T, n_ax)[:, 1:, :],
-                   upos=tag_idx[0].view(B, T)[:, 1:], attrs=tag_idx[1].view(B, T)[:, 1:],
-                   xpos=tag_idx[2].view(B, T)[:, 1:])
+        return dict(tag_idx=tag_idx,
+                    upos_logits=upos_log.view(B, T, n_u)[:, root:, :], ax_logits=ax_log.view(B, T, n_ax)[:, root:, :],
+                    upos=tag_idx[0].view(B, T)[:, root:], attrs=tag_idx[1].view(B, T)[:, root:],
+                    xpos=tag_idx[2].view(B, T)[:, root:])
+
+
+class Parser(_HipNet):
+    _root = 1
+    _pack = staticmethod(packing.pack_parser)
+
+    def __init__(self, config, encodings, language_codes=None, ext_word_emb=0):
+        super().__init__(config, encodings, language_codes, ext_word_emb)
+        self._decoder = ChuLiuEdmondsDecoder()
+        self._streams = None
+
+    def _front(self, bt, slot=0, want_aux=False):
+        """GEMM-heavy first phase: char CNN, ext MLPs, word CNN, morphology heads.  Leaves the LSTM
+        input in xl0_{slot} and the tag logits in slot buffers."""
+        pk, lay, buf, st = self._pk, self._lay, self._buf, hip.stream_handle()
+        BT = bt["B"] * bt["T"]
+        wh, lg, P = lay.word_half, lay.lang, lay.P
+        # XL0 = [x_parse | lang | ext] (LSTM input), XM = [hidden | lang] (morphology input)
+        xl0_w = p32(wh + lg + P)
+        xl0 = buf.get("xl0_%d" % slot, BT, xl0_w)
+        self._zero(xl0, BT * xl0_w)
+        xm_w = p32(wh + lg)
+        xm = buf.get("xm", BT, xm_w)
+        out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,
+                          ext_b_col=wh + lg, want_aux=want_aux)
+        # ---- morphology heads (parser.py:178-192); PM = [pre_morpho | lang | upos_emb]
+        pm_w = p32(wh + lg + 64)
+        pm = buf.get("pm", BT, pm_w)
+        self._gather(pm, pm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        q = pk["pre_morpho"]
+        hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
+                 n_valid=q["n_valid"], stream=st)
+        out.update(self._tag_heads(bt, slot, pm, pm_w, "upos", wh + lg))
+        out.update(xl0=xl0, xl0_w=xl0_w)
         return out
 
     def _back(self, bt, fr, slot=0):

@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 1
+        return 2
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -130,11 +130,12 @@ class TraceLib:
             self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
         return 0
 
-    def cube_ext_finish(self, acc, ld_acc, B, L, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):
+    def cube_ext_finish(self, acc, ld_acc, B, L, root, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):
         self.calls.append(("ext_finish", B, L, P))
-        assert P <= ld_acc and col_a + P <= ld_a and col_b + P <= ld_b
+        assert P <= ld_acc and col_a + P <= ld_a and (db is None or col_b + P <= ld_b)
         self._need("ext_finish acc", acc, 4 * ((B * L - 1) * ld_acc + P), 4)
-        last = B * (L + 1) - 1
+        assert root in (0, 1)
+        last = B * (L + root) - 1
         for nm, p, ld, c in (("a", da, ld_a, col_a), ("a_lo", da_lo, ld_a, col_a), ("b", db, ld_b, col_b),
                              ("b_lo", db_lo, ld_b, col_b)):
             self._need("ext_finish dst_" + nm, p, 2 * (last * ld + c + P), 2)
@@ -203,11 +204,11 @@ class TraceLib:
         return 0
 
 
-def dry_parser(case_cfg, enc, sd, ext, precision, monkeypatch):
-    """A Parser whose device is the host and whose library is a TraceLib."""
+def dry_net(cls, case_cfg, enc, sd, ext, precision, monkeypatch):
+    """A Parser / Tagger whose device is the host and whose library is a TraceLib."""
     from cube_amd.networks import packing
     from cube_amd.networks import parser as parser_mod
-    p = parser_mod.Parser(case_cfg, enc, ext_word_emb=list(ext))
+    p = cls(case_cfg, enc, ext_word_emb=list(ext))
     p.precision = precision
     p.load_state_dict(sd)
     p._device = torch.device("cpu")
@@ -219,3 +220,8 @@ def dry_parser(case_cfg, enc, sd, ext, precision, monkeypatch):
     monkeypatch.setattr(hip, "stream_handle", lambda: 0)
     monkeypatch.setattr(p, "_require_gpu", lambda: None)
     return p, lib
+
+
+def dry_parser(case_cfg, enc, sd, ext, precision, monkeypatch):
+    from cube_amd.networks.parser import Parser
+    return dry_net(Parser, case_cfg, enc, sd, ext, precision, monkeypatch)

@@ -195,10 +195,28 @@ def g7_tagger():
     print("g7", len(save), "arrays")
 
 
+def g8_tagger_process():
+    """Tagger.process end to end: CoNLL-U text of the g6 document at the reference's default
+    batch size (32) and at 4 (results depend on batch composition)."""
+    for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
+        cfg, enc, sd = cases.tagger_model(case)
+        t = REF["Tagger"](ref_config("TaggerConfig", cfg), ref_encodings(enc), language_codes=synth.EN_LANGUAGE_CODES,
+                          ext_word_emb=list(case["ext"]))
+        t.load_state_dict(sd, strict=True)
+        t.eval()
+        col = REF["MorphoCollate"](ref_encodings(enc))
+        for bs in (4, 32):
+            doc = ref_document(cases.document(case, enc, "g6"))
+            t.process(doc, col, batch_size=bs, num_workers=0)
+            with open(os.path.join(HERE, "g8_tagger_process_%s_bs%d.conllu" % (tag, bs)), "w", encoding="utf-8") as f:
+                f.write(str(doc))
+            print("g8", tag, bs)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8"]
     if "g1" in which:
         g1_collate()
     if "g2" in which:
@@ -211,3 +229,5 @@ if __name__ == "__main__":
         g6_process()
     if "g7" in which:
         g7_tagger()
+    if "g8" in which:
+        g8_tagger_process()

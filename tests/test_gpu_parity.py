@@ -315,3 +315,70 @@ def test_process_document_text_matches_reference(dev, golden_dir, tag, case, bs)
     assert len(got) == len(exp)
     diff = sum(x != y for x, y in zip(got, exp))
     assert diff <= len(got) // 1000, diff
+
+
+# ------------------------------------------------------------------------------------------
+# stand-alone Tagger against the REFERENCE's outputs (golden G7, G8)
+# ------------------------------------------------------------------------------------------
+def _tagger(dev, case, precision="bf16x3"):
+    from cube_amd.networks.tagger import Tagger
+    key = (case["name"], precision)
+    if key not in _MODELS:
+        cfg, enc, sd = cases.tagger_model(case)
+        t = Tagger(cfg, enc, ext_word_emb=list(case["ext"]))
+        t.precision = precision
+        t.load_state_dict(sd)
+        t.to(dev)
+        _MODELS[key] = (t, cfg, enc, sd)
+    return _MODELS[key]
+
+
+@pytest.mark.parametrize("tag,case", [("tiny", cases.TINY_TAGGER), ("full", cases.FULL_TAGGER)])
+def test_tagger_forward_matches_reference(dev, golden_dir, tag, case):
+    """Tagger.forward: all six logit tensors within 1e-3 relative of the reference's (G7);
+    arg-max decisions equal wherever the reference's top-2 margin exceeds the tolerance."""
+    from cube_amd.networks.utils import MorphoCollate
+    g = np.load(os.path.join(golden_dir, "g7_tagger.npz"))
+    t, cfg, enc, sd = _tagger(dev, case)
+    doc = cases.document(case, enc, "ragged")
+    X = MorphoCollate(enc).collate_fn(doc.sentences)
+    X.pop("y_upos")
+    outs = t.forward(X)
+    sl = X["x_sent_len"].numpy()
+    mask = np.arange(X["x_sent"].shape[1])[None, :] < sl[:, None]
+    got = {k: v.cpu().numpy() for k, v in zip(("upos", "xpos", "attrs", "aupos", "axpos", "aattrs"), outs)}
+    for k in ("upos", "aupos", "axpos", "aattrs"):
+        ref = g["%s/ragged/%s" % (tag, k)]
+        assert got[k].shape == ref.shape, k
+        assert _rel(got[k], ref) < REL_TOL, (k, _rel(got[k], ref))
+    ref_u = g["%s/ragged/upos" % tag]
+    same = np.argmax(got["upos"], -1) == np.argmax(ref_u, -1)  # xpos / attrs are conditioned on the UPOS decision
+    nbad, agree = _margin_ok(ref_u[mask], np.argmax(got["upos"], -1)[mask], np.argmax(ref_u, -1)[mask],
+                             REL_TOL * np.abs(ref_u).max())
+    assert nbad == 0 and agree >= 0.999, (nbad, agree)
+    for k in ("xpos", "attrs"):
+        ref = g["%s/ragged/%s" % (tag, k)]
+        assert _rel(got[k][same], ref[same]) < REL_TOL, (k, _rel(got[k][same], ref[same]))
+
+
+@pytest.mark.parametrize("tag,case", [("tiny", cases.TINY_TAGGER), ("full", cases.FULL_TAGGER)])
+@pytest.mark.parametrize("bs", [4, 32])
+def test_tagger_process_text_matches_reference(dev, golden_dir, tag, case, bs):
+    """Tagger.process end to end against the REFERENCE's CoNLL-U text (golden G8)."""
+    from cube_amd.networks.utils import MorphoCollate
+    t, cfg, enc, sd = _tagger(dev, case)
+    doc = cases.document(case, enc, "g6")
+    t.process(doc, MorphoCollate(enc), batch_size=bs, num_workers=0)
+    with open(os.path.join(golden_dir, "g8_tagger_process_%s_bs%d.conllu" % (tag, bs)), encoding="utf-8") as f:
+        exp = f.read().split("\n")
+    got = str(doc).split("\n")
+    assert len(got) == len(exp)
+    diff = sum(x != y for x, y in zip(got, exp))
+    assert diff <= len(got) // 1000, diff
+
+
+def test_tagger_process_needs_a_flag(dev):
+    from cube_amd.networks.utils import MorphoCollate
+    t, cfg, enc, sd = _tagger(dev, cases.TINY_TAGGER)
+    with pytest.raises(Exception):
+        t.process(cases.document(cases.TINY_TAGGER, enc, "single"), MorphoCollate(enc), upos=False, xpos=False, attrs=False)

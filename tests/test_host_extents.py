@@ -72,3 +72,23 @@ def test_tracer_catches_a_short_buffer(monkeypatch):
     monkeypatch.setattr(p._buf, "get", short_get)
     with pytest.raises(ExtentError):
         p.decode_batch_prepared(bt)
+
+
+@pytest.mark.parametrize("case", [cases.TINY_TAGGER, cases.FULL_TAGGER])
+def test_tagger_extents(monkeypatch, case):
+    from tests.abi_trace import dry_net
+    from cube_amd.networks.tagger import Tagger
+    from cube_amd.networks.utils import MorphoCollate
+    cfg, enc, sd = cases.tagger_model(case)
+    t, lib = dry_net(Tagger, cfg, enc, sd, case["ext"], "bf16x3", monkeypatch)
+    for key in ("single", "ragged", "g6"):
+        doc = cases.document(case, enc, key)
+        X = MorphoCollate(enc).collate_fn(doc.sentences)
+        outs = t.forward(X)  # gold-tag path + aux heads
+        B, L = X["x_sent"].shape
+        assert len(outs) == 6 and all(tuple(o.shape)[:2] == (B, L) for o in outs)
+        X.pop("y_upos")
+        r = t.tag_batch(X)
+        assert tuple(r["packed"].shape) == (3, B, L)
+    names = [c[0] for c in lib.calls]
+    assert "bilstm" not in names and "mst" not in names

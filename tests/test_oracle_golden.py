@@ -106,6 +106,18 @@ def test_g7_tagger_matches_reference(golden_dir):
             np.testing.assert_allclose(v.numpy(), g["%s/ragged/%s" % (tag, k)], err_msg=k, **FP32_TOL)
 
 
+@pytest.mark.parametrize("tag,case", [("tiny", cases.TINY_TAGGER), ("full", cases.FULL_TAGGER)])
+@pytest.mark.parametrize("bs", [4, 32])
+def test_g8_tagger_process_text_matches_reference(golden_dir, tag, case, bs):
+    cfg, enc, sd = cases.tagger_model(case)
+    net = parser_oracle.OracleTagger(cfg, enc, sd, list(case["ext"]), quant="fp32")
+    doc = cases.document(case, enc, "g6")
+    net.process(doc, batch_size=bs)
+    with open(os.path.join(golden_dir, "g8_tagger_process_%s_bs%d.conllu" % (tag, bs)), encoding="utf-8") as f:
+        exp = f.read()
+    assert str(doc) == exp
+
+
 def test_bf16_mode_close_to_fp32_mode():
     """The HIP arithmetic contract (bf16 operands, fp32 accumulate) stays near the reference's
     fp32 arithmetic: sanity bound on arc logits, and decisions agree where margins are large."""
