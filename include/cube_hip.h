@@ -63,7 +63,16 @@ enum {
  * g = tanh(C_a) * sigmoid(C_b) per channel ch.  Then
  *   res (optional) res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g
  *   out0 (bf16, optional): [row, col0+ch] = g
- *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference) */
+ *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference)
+ *
+ * Broadcast input channels folded into the bias (CUBE_EPI_GATE only).  The reference
+ * concatenates the language embedding to every position of a sequence before each Conv1d
+ * (modules.py:470, parser.py:165-175): those channels are constant along the sequence, so their
+ * contribution to C[r, n] depends only on the row's language and on WHICH taps of r fall inside
+ * its sequence.  With bias_tab / row_group given, bias[n] is replaced by
+ *   bias_tab[(row_group[r] * 32 + tapmask(r)) * N + n],   tapmask bit t = tap t is inside,
+ * computed at load time (bias + sum over inside taps of W_lang[n, tap, :] . emb[group]), and the
+ * GEMM runs over the remaining channels only.  bias_tab f32 [n_groups, 32, N]; row_group i32 [M]. */
 typedef struct cube_gemm_args {
   const void* A; const void* A_lo; int lda; int M; int seq_len; int taps; int Kc;
   const void* W; const void* W_lo; int N; const float* bias;
@@ -73,6 +82,7 @@ typedef struct cube_gemm_args {
   float* res; int ld_res; int res_mode;
   void* out1; void* out1_lo; int ldo1; int col1;
   void* out2; void* out2_lo; int ldo2; int col2;
+  const float* bias_tab; const int32_t* row_group; int n_groups;
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 

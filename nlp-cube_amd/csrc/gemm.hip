@@ -47,6 +47,9 @@ struct GemmParams {
   float* res; int ld_res; int res_mode;
   uint16_t* out1; uint16_t* out1_lo; int ldo1; int col1;
   uint16_t* out2; uint16_t* out2_lo; int ldo2; int col2;
+  int m_tiles; int n_tiles;  // set by launch_cfg
+  int vec_out;               // gate epilogue without residual: 16-byte row-contiguous stores are legal
+  const float* bias_tab; const int32_t* row_group;  // row-dependent bias (broadcast channels folded in)
 };
 
 __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t idx, float v) {
@@ -95,8 +98,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / C::WN, wc = wid % C::WN;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // 1-D grid, XCD-aware: workgroups go round-robin over the 8 XCDs (each with its own L2), so the
+  // N-tiles that share one row tile (= the same activation slab) are given consecutive slots of
+  // the SAME XCD and the slab crosses HBM -> L2 once.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / p.n_tiles) * 8 + xcd;
+  if (mt >= p.m_tiles) return;  // whole block: before any barrier
+  const int m0 = mt * BM;
+  const int n0 = (slot % p.n_tiles) * BN;
   const int taps = p.taps;
   const int half_taps = taps >> 1;
   const int nkc = p.Kc / BK;
@@ -154,21 +163,23 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define ISSUE_A(KC, BUF)                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_) {                                         \
-    const int q_ = wid + NW * i_;                                                             \
+#define ISSUE_A_PIECE(KC, BUF, I)                                                             \
+  {                                                                                           \
+    const int q_ = wid + NW * (I);                                                            \
     if (q_ < A_PIECES) {                                                                      \
       unsigned char* l_ = smem + (BUF) * A_BUF + q_ * 1024;                                   \
-      glds16(p.A + a_src[i_] + (KC) * BK, l_);                                                \
-      if constexpr (SPLIT) glds16(p.A_lo + a_src[i_] + (KC) * BK, l_ + A_PLANE);              \
+      glds16(p.A + a_src[I] + (KC) * BK, l_);                                                 \
+      if constexpr (SPLIT) glds16(p.A_lo + a_src[I] + (KC) * BK, l_ + A_PLANE);               \
     }                                                                                         \
   }
-#define ISSUE_B(S, BUF)                                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_) {                                         \
-    unsigned char* l_ = smem + B_BASE + (BUF) * B_BUF + (wid + NW * i_) * 1024;               \
-    glds16(p.W + b_src[i_] + (size_t)(S) * BK, l_);                                           \
-    if constexpr (SPLIT) glds16(p.W_lo + b_src[i_] + (size_t)(S) * BK, l_ + B_PLANE);         \
+#define ISSUE_B_PIECE(S, BUF, I)                                                              \
+  {                                                                                           \
+    unsigned char* l_ = smem + B_BASE + (BUF) * B_BUF + (wid + NW * (I)) * 1024;              \
+    glds16(p.W + b_src[I] + (size_t)(S) * BK, l_);                                            \
+    if constexpr (SPLIT) glds16(p.W_lo + b_src[I] + (size_t)(S) * BK, l_ + B_PLANE);          \
   }
+#define ISSUE_A(KC, BUF) _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_) ISSUE_A_PIECE(KC, BUF, i_)
+#define ISSUE_B(S, BUF) _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_) ISSUE_B_PIECE(S, BUF, i_)
 
   ISSUE_A(0, 0)
   ISSUE_B(0, 0)
@@ -177,10 +188,10 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   int kc = 0, tap = 0;
   for (int s = 0; s < nk; ++s) {
     const bool last_tap = (tap == taps - 1);
-    if (s + 1 < nk) {
-      ISSUE_B(s + 1, (s + 1) & 1)
-      if (last_tap) { ISSUE_A(kc + 1, (kc + 1) & 1) }
-    }
+    // next step's operands: one LDS-DMA piece after each MFMA group below (a piece costs the wave
+    // 60-180 issue cycles; spread out, the queued MFMAs cover it, bunched at the top they do not)
+    const bool more = s + 1 < nk;
+    constexpr int PPU = (PA + PB + 2 * TM - 1) / (2 * TM);  // pieces per MFMA group
     const unsigned char* bbase = smem + B_BASE + (s & 1) * B_BUF;
     // fragment reads run one (k-substep, row tile) unit ahead of the MFMAs that consume them
     int aoff[TM], alo[TM];  // LDS byte offsets of this lane's A fragment (k-substep 0) and hi->lo distance
@@ -224,12 +235,24 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
       }
+      if (more) {
+#pragma unroll
+        for (int q = u * PPU; q < (u + 1) * PPU && q < PA + PB; ++q) {
+          if (q < PB) {
+            ISSUE_B_PIECE(s + 1, (s + 1) & 1, q)
+          } else if (last_tap) {
+            ISSUE_A_PIECE(kc + 1, (kc + 1) & 1, q - PB)
+          }
+        }
+      }
     }
     __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
     if (last_tap) { tap = 0; ++kc; } else { ++tap; }
   }
 #undef ISSUE_A
 #undef ISSUE_B
+#undef ISSUE_A_PIECE
+#undef ISSUE_B_PIECE
 
   // ---- epilogue.  C/D map of 32x32x16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int wrow0 = m0 + wr * (BM / C::WM);
@@ -238,25 +261,94 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     const int ch = wcol0 / 2 + l31;
     const float bias_a = p.bias[wcol0 + l31];
     const float bias_b = p.bias[wcol0 + 32 + l31];
+    const float* __restrict__ btab = p.bias_tab;
+    // offset (floats) of row r's bias vector inside bias_tab
+    auto tab_off = [&](int row) -> size_t {
+      const int pos = row % p.seq_len;
+      unsigned m = 0;
+      for (int t = 0; t < taps; ++t) {
+        const int pp = pos + t - half_taps;
+        if (pp >= 0 && pp < p.seq_len) m |= 1u << t;
+      }
+      return ((size_t)p.row_group[row] * 32 + m) * p.N + wcol0 + l31;
+    };
     float* __restrict__ res = p.res;
     uint16_t* __restrict__ out0 = reinterpret_cast<uint16_t*>(p.out0);
     uint16_t* __restrict__ out0_lo = p.out0_lo;
     const bool ch_ok = ch < p.n_valid;
     const int res_mode = p.res_mode;
+    if (p.vec_out) {
+      // no residual stream (character CNN): transpose each 32x32 gate tile through wave-private LDS
+      // (the operand images are dead after the last barrier) and store 16 bytes per lane, 64-byte
+      // row segments, instead of 2-byte scattered stores.
+      constexpr int SROW = 80;  // bytes per staged row: 16-byte aligned, the two half-waves hit disjoint banks
+      unsigned char* stg = smem + wid * (NP * 32 * SROW);
+      const int srow = lane >> 2, schunk = lane & 3;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float ba[16], bb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (btab && row < p.M) {
+            const size_t o = tab_off(row);
+            ba[r] = btab[o];
+            bb[r] = btab[o + 32];
+          } else {
+            ba[r] = bias_a;
+            bb[r] = bias_b;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
+          uint16_t h, l = 0;
+          if constexpr (SPLIT) split_bf16(g, h, l); else h = f32_to_bf16(g);
+          *reinterpret_cast<uint16_t*>(stg + lr * SROW + l31 * 2) = h;
+          if constexpr (SPLIT) *reinterpret_cast<uint16_t*>(stg + 32 * SROW + lr * SROW + l31 * 2) = l;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cbase = wcol0 / 2 + schunk * 8;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int lr = srow + 16 * hh;
+          const int row = wrow0 + i * 32 + lr;
+          if (row < p.M && cbase < p.n_valid) {
+            const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;
+            *reinterpret_cast<uint4*>(out0 + o) = *reinterpret_cast<const uint4*>(stg + lr * SROW + schunk * 16);
+            if constexpr (SPLIT)
+              *reinterpret_cast<uint4*>(out0_lo + o) = *reinterpret_cast<const uint4*>(stg + 32 * SROW + lr * SROW + schunk * 16);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // all residual loads of this 32-row tile first (independent, in flight together), then the math
-      float rv[16];
+      float rv[16], ba[16], bb[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         rv[r] = (res && res_mode != 0 && ch_ok && row < p.M) ? res[(size_t)row * p.ld_res + ch] : 0.f;
+        if (btab && row < p.M) {
+          const size_t o = tab_off(row);
+          ba[r] = btab[o];
+          bb[r] = btab[o + 32];
+        } else {
+          ba[r] = bias_a;
+          bb[r] = bias_b;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.M && ch_ok) {
-          const float g = tanhf_(acc[i][0][r] + bias_a) * sigmoidf_(acc[i][1][r] + bias_b);
+          const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
           if (out0) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
           if (!res) continue;  // plain gated layer: no residual stream
           const float rs = rv[r] + (res_mode == 2 ? 2.0f * g : g);
@@ -299,7 +391,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 }
 
 template <int EPI, bool SPLIT, class C>
-int launch_cfg(const GemmParams& p, hipStream_t st) {
+int launch_cfg(GemmParams p, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
@@ -308,7 +400,9 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
       CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
     attr_set = true;
   }
-  dim3 grid(p.N / C::BN, (p.M + C::BM - 1) / C::BM);
+  p.n_tiles = p.N / C::BN;
+  p.m_tiles = (p.M + C::BM - 1) / C::BM;
+  dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
   hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p);
   return CUBE_OK;
 }
@@ -340,6 +434,12 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   const int seq = a->taps == 1 ? a->M : a->seq_len;
   if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: M=%d not a multiple of seq_len=%d", a->M, seq);
   GemmParams p;
+  p.vec_out = 0; p.m_tiles = p.n_tiles = 0;
+  p.bias_tab = a->bias_tab; p.row_group = a->row_group;
+  if ((a->bias_tab == nullptr) != (a->row_group == nullptr))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab and row_group go together");
+  if (a->bias_tab && (a->epilogue != CUBE_EPI_GATE || a->taps > 5 || a->n_groups <= 0))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab needs the gate epilogue, taps <= 5 and n_groups > 0");
   p.A = (const uint16_t*)a->A; p.A_lo = (const uint16_t*)a->A_lo; p.lda = a->lda; p.M = a->M; p.seq_len = seq;
   p.taps = a->taps; p.Kc = a->Kc;
   p.W = (const uint16_t*)a->W; p.W_lo = (const uint16_t*)a->W_lo; p.N = a->N; p.bias = a->bias;
@@ -377,6 +477,8 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
       if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out1/ldo1");
       if (a->out2 && a->ldo2 < a->col2 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out2/ldo2");
       if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
+      p.vec_out = !a->res && a->out0 && half % 8 == 0 && a->ldo0 % 8 == 0 && a->col0 % 8 == 0 && aligned16(a->out0) &&
+                  aligned16(a->out0_lo);
       rc = launch<CUBE_EPI_GATE>(p, st);
       break;
     }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 2  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 3  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -26,6 +26,7 @@ class GemmArgs(ctypes.Structure):
         ("res", c_void_p), ("ld_res", c_int), ("res_mode", c_int),
         ("out1", c_void_p), ("out1_lo", c_void_p), ("ldo1", c_int), ("col1", c_int),
         ("out2", c_void_p), ("out2_lo", c_void_p), ("ldo2", c_int), ("col2", c_int),
+        ("bias_tab", c_void_p), ("row_group", c_void_p), ("n_groups", c_int),
     ]
 
 
@@ -130,7 +131,7 @@ def _planes(x, col=0):
 
 def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
          rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
-         a_col=0, stream=None):
+         a_col=0, bias_tab=None, row_group=None, stream=None):
     """A, W, out0 (bf16 epilogues), out1, out2: `Pair`s; out0 of CUBE_EPI_F32: an fp32 tensor.
     bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements)."""
     a = GemmArgs()
@@ -152,6 +153,8 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     a.ldo1, a.col1 = ldo1, col1
     a.out2, a.out2_lo = _planes(out2)
     a.ldo2, a.col2 = ldo2, col2
+    a.bias_tab, a.row_group = ptr(bias_tab), ptr(row_group)
+    a.n_groups = 0 if bias_tab is None else bias_tab.shape[0]
     check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")
 
 

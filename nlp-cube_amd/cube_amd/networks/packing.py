@@ -49,9 +49,15 @@ def gate_column_order(half):
     return order
 
 
-def pack_gated_conv(sd, prefix, in_perm, double_first=0):
+def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None):
     """-> dict(W bf16 [N, taps*Kc], bias f32 [N], Kc, N, half).
-    in_perm: for each column of the HIP activation buffer, the reference input channel (or -1)."""
+    in_perm: for each column of the HIP activation buffer, the reference input channel (or -1).
+    bcast = (reference channels, table [G, len(channels)]): input channels that carry the same
+    vector table[g] at every position of a sequence (the language embedding the reference
+    concatenates before each conv).  They are left out of the GEMM; their contribution goes into
+    `bias_tab` f32 [G, 32, N]: entry [g, m] = bias + sum over the taps t in bit mask m of
+    W[:, channels, t] @ table[g]  (m = the taps that fall inside the sequence at a position).
+    `bias_tab_q` is the same from bf16-rounded weights and table (single-pass "bf16" contract)."""
     w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
     b = sd[prefix + ".0.conv.bias"].float()
     s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
@@ -79,7 +85,20 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0):
     bias[valid_n] = b[src_n]
     # K order of cube_gemm_bf16: 32-channel chunk outer, tap inner
     W = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)
-    return dict(W=_bf16(W), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
+    out = dict(W=_bf16(W), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
+    if bcast is not None:
+        chans, table = bcast
+        chans = torch.as_tensor(np.asarray(chans), dtype=torch.long)
+        assert taps <= 5
+        for key, q in (("bias_tab", lambda t: t.double()), ("bias_tab_q", lambda t: t.to(torch.bfloat16).double())):
+            wl = q(w[:, chans, :])                                        # [F, C, taps] (BN already folded in)
+            contrib = torch.einsum("gc,fct->gtf", q(table.float()), wl)   # [G, taps, F]
+            masks = torch.tensor([[(m >> t) & 1 for t in range(taps)] for m in range(32)], dtype=torch.float64)
+            tab = torch.einsum("mt,gtf->gmf", masks, contrib) + b.double()[None, None, :]   # [G, 32, F]
+            packed = torch.zeros((table.shape[0], 32, N), dtype=torch.float32)
+            packed[:, :, valid_n] = tab[:, :, src_n].float()
+            out[key] = packed.contiguous()
+    return out
 
 
 def pack_linear(w, b, in_perm=None, out_rows=None, n_pad=None):
@@ -124,18 +143,17 @@ class Layout:
         self.char_emb, self.case_emb, self.lang = cfg.char_emb_size, 32, cfg.lang_emb_size
         self.char_half, self.word_half = cfg.char_filter_size // 2, cfg.cnn_filter // 2
         self.word_emb, self.P = cfg.word_emb_size, cfg.external_proj_size
-        # XC0: [tok | case | lang]  (reference order, modules.py:455,470)
-        self.xc0_w = p32(self.char_emb + self.case_emb + self.lang)
-        self.xc0_lang = self.char_emb + self.case_emb
-        # XC (layers >= 1): [g | lang]
-        self.xc_w = p32(self.char_half + self.lang)
+        # XC0: [tok | case]; XC (layers >= 1): [g].  The language embedding the reference concatenates
+        # to every position (modules.py:455,470) is folded into a per-(language, tap mask) bias table.
+        self.xc0_w = p32(self.char_emb + self.case_emb)
+        self.xc_w = p32(self.char_half)
         # XW0: [word | char | lang | ext]   (reference: word, char, ext, lang — parser.py:149-151)
         self.xw0_char = self.word_emb
         self.xw0_lang = self.word_emb + self.char_half
         self.xw0_ext = self.xw0_lang + self.lang
         self.xw0_n = self.xw0_ext + self.P
         self.xw0_w = p32(self.xw0_n)
-        self.xw_w = p32(self.word_half + self.lang)  # [g | lang]
+        self.xw_w = p32(self.word_half)  # [g]; lang folded into the bias table of layers >= 1
 
     def xw0_perm(self):
         """buffer column -> reference channel of the first word-level conv / of `_r_emb`."""
@@ -153,12 +171,13 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
     pk["tok_emb"] = pack_table(sd["_word_net._tok_emb.weight"])
     pk["case_emb"] = pack_table(sd["_word_net._case_emb.weight"])
     pk["wn_lang_emb"] = pack_table(sd["_word_net._lang_emb.weight"])
-    c0 = lay.char_emb + lay.case_emb + lay.lang
     pk["char_convs"] = []
+    wn_lang = sd["_word_net._lang_emb.weight"].float()
     for l in range(cfg.char_layers):
-        cin = c0 if l == 0 else lay.char_half + lay.lang
+        cin = lay.char_emb + lay.case_emb if l == 0 else lay.char_half  # then come the lang channels
         pk["char_convs"].append(pack_gated_conv(sd, "_word_net._convolutions_char.%d" % l, np.arange(cin),
-                                                double_first=lay.char_half if l > 0 else 0))
+                                                double_first=lay.char_half if l > 0 else 0,
+                                                bcast=(cin + np.arange(lay.lang), wn_lang)))
     pk["char_pre_out"] = pack_linear(sd["_word_net._pre_out.linear_layer.weight"], sd["_word_net._pre_out.linear_layer.bias"])
     pk["ext"] = []
     for i, e in enumerate(ext_dims):
@@ -171,9 +190,14 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
     pk["lang_emb"] = pack_table(sd["_lang_emb.weight"])
     perm0 = lay.xw0_perm()
     pk["word_convs"] = []
+    lang_tab = sd["_lang_emb.weight"].float()
     for l in range(cfg.cnn_layers):
-        perm = perm0 if l == 0 else np.arange(lay.word_half + lay.lang)
-        pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, perm))
+        # layer 0 keeps its lang channels in the GEMM (the parser's root row carries its own, parser.py:153-156)
+        if l == 0:
+            pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, perm0))
+        else:
+            pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, np.arange(lay.word_half),
+                                                    bcast=(lay.word_half + np.arange(lay.lang), lang_tab)))
     # aux heads read [char_emb | lang], contiguous inside XW0
     n_u, n_x, n_a = enc_sizes["upos"], enc_sizes["xpos"], enc_sizes["attrs"]
     w = torch.cat([sd["_aupos.linear_layer.weight"], sd["_axpos.linear_layer.weight"], sd["_aattrs.linear_layer.weight"]], 0)
@@ -286,13 +310,18 @@ def pack_tagger(sd, cfg, enc_sizes, ext_dims):
 
 
 def to_device(obj, device, with_lo=True):
+    """Upload; bf16x3 (with_lo) keeps both planes and the exact bias tables, single-pass bf16 keeps
+    the hi plane and the tables built from bf16-rounded operands."""
     from cube_amd.hip import Pair
     if isinstance(obj, Pair):
         return Pair(obj.hi.to(device), obj.lo.to(device) if (with_lo and obj.lo is not None) else None)
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
     if isinstance(obj, dict):
-        return {k: to_device(v, device, with_lo) for k, v in obj.items()}
+        out = {k: to_device(v, device, with_lo) for k, v in obj.items() if k != "bias_tab_q"}
+        if "bias_tab_q" in obj and not with_lo:
+            out["bias_tab"] = obj["bias_tab_q"].to(device)
+        return out
     if isinstance(obj, list):
         return [to_device(v, device, with_lo) for v in obj]
     return obj

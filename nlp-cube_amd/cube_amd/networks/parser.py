@@ -235,18 +235,17 @@ class _HipNet:
         xc0 = buf.get("xc0", NW, lay.xc0_w)
         gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, NW)
         gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, NW)
-        gather(xc0, lay.xc0_w, lay.xc0_lang, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
         nchar = len(pk["char_convs"])
-        # every gated layer keeps its own output g_l = [g | lang]: the next layer reads it, and the
-        # masked mean sums them (no fp32 residual stream through HBM at N*W rows)
+        # every gated layer keeps its own output g_l: the next layer reads it, and the masked mean
+        # sums them (no fp32 residual stream through HBM at N*W rows).  The language channels are
+        # not materialised: they enter through the per-(language, tap mask) bias table.
         gl = [buf.get("xc_g%d" % l, NW, lay.xc_w) for l in range(nchar)]
         src, src_ld = xc0, lay.xc0_w
         for l, cv in enumerate(pk["char_convs"]):
-            if l + 1 < nchar:
-                gather(gl[l], lay.xc_w, ch, lg, pk["wn_lang_emb"], bt["lang_char"], None, NW)
             with self._timed("char_conv" if l > 0 else "char_conv0"):
                 hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
-                         ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"], stream=st)
+                         ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"],
+                         bias_tab=cv["bias_tab"], row_group=bt["lang_char"], stream=st)
             src, src_ld = gl[l], lay.xc_w
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
@@ -285,7 +284,7 @@ class _HipNet:
         # ---- word-level gated CNN
         xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
         resw = buf.get("resw", BT, wh, torch.float32)
-        for dstb, ldb in [(xwa, lay.xw_w), (xwb, lay.xw_w)] + list(lang_dsts):
+        for dstb, ldb in lang_dsts:
             gather(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         nword = len(pk["word_convs"])
         src, src_ld = xw0, lay.xw0_w
@@ -296,7 +295,8 @@ class _HipNet:
             o1, o2 = (tap if aux_here else None), (final if last else None)
             hip.gemm(src, src_ld, BT, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
                      col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh,
-                     res_mode=0 if l == 0 else 1, out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0, stream=st)
+                     res_mode=0 if l == 0 else 1, out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0,
+                     bias_tab=cv.get("bias_tab"), row_group=bt["lang_rows"] if "bias_tab" in cv else None, stream=st)
             src, src_ld = dst, lay.xw_w
         return out
 

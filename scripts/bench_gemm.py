@@ -1,4 +1,4 @@
-"""Micro-benchmark of cube_gemm_bf16 at the char-conv shape (GPU box): python scripts/bench_gemm.py [split] [M]"""
+"""Micro-benchmark of cube_gemm_bf16 at the char-conv shape (GPU box): python scripts/bench_gemm.py [split] [M] [res]"""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,11 +14,12 @@ g = torch.Generator().manual_seed(0)
 A = hip.Pair.split(torch.randn((M, Kc), generator=g), split).to(dev)
 Wt = hip.Pair.split(torch.randn((N, taps * Kc), generator=g) / 40, split).to(dev)
 bias = torch.randn(N, generator=g).to(dev)
-res = torch.zeros((M, half), device=dev)
+use_res = (sys.argv[3] if len(sys.argv) > 3 else "0") == "1"
+res = torch.zeros((M, half), device=dev) if use_res else None
 out = hip.Pair(torch.zeros((M, Kc), dtype=torch.bfloat16, device=dev), torch.zeros((M, Kc), dtype=torch.bfloat16, device=dev) if split else None)
 def run():
     hip.gemm(A, Kc, M, Kc, Wt, N, bias, hip.EPI_GATE, out0=out, ldo0=Kc, col0=0, taps=taps, seq_len=W_, n_valid=half,
-             res=res, ld_res=half, res_mode=1)
+             res=res, ld_res=half if use_res else 0, res_mode=1 if use_res else 0)
 for _ in range(3): run()
 torch.cuda.synchronize()
 n = 20

@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 2
+        return 3
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -87,6 +87,11 @@ class TraceLib:
         gate = a.epilogue == hip.EPI_GATE
         nv = a.n_valid if a.n_valid > 0 else (N // 2 if gate else N)
         self._need("gemm bias", a.bias, 4 * (N if gate else nv), 4)
+        if a.bias_tab:
+            assert gate and a.row_group and taps <= 5 and a.n_groups > 0
+            grp = self._ints("gemm row_group", a.row_group, M)
+            assert grp.min() >= 0 and grp.max() < a.n_groups
+            self._need("gemm bias_tab", a.bias_tab, 4 * a.n_groups * 32 * N, 4)
         rows = M
         if a.rowmap:
             rm = self._ints("gemm rowmap", a.rowmap, M)
