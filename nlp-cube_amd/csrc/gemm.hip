@@ -33,9 +33,10 @@ struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
 constexpr int MAX_TAPS = 5;
 // slab rows allocated in LDS: tile rows + halo, rounded to the 16 rows one LDS-DMA piece fills
 template <class C> constexpr int slab_rows() { return (C::BM + MAX_TAPS - 1 + 15) / 16 * 16; }
-// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row]; every buffer holds NP planes
+// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row][bias-table offset per tile row];
+// every operand buffer holds NP planes
 template <class C, bool SPLIT> constexpr int lds_bytes() {
-  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB;
+  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + C::BM * 4;
 }
 
 struct GemmParams {
@@ -113,6 +114,23 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int ktot = taps * p.Kc;
 
   if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
+  // row-dependent bias: offset of each tile row's bias vector (one modulo per row, done once here;
+  // visible to the epilogue through the barriers of the main loop)
+  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB;
+  if (p.bias_tab && tid < BM) {
+    const int row = m0 + tid;
+    unsigned off = 0;
+    if (row < p.M) {
+      const int pos = row % p.seq_len;
+      unsigned m = 0;
+      for (int t = 0; t < taps; ++t) {
+        const int pp = pos + t - half_taps;
+        if (pp >= 0 && pp < p.seq_len) m |= 1u << t;
+      }
+      off = ((unsigned)p.row_group[row] * 32u + m) * (unsigned)p.N;
+    }
+    reinterpret_cast<uint32_t*>(smem + ROWOFF_OFF)[tid] = off;
+  }
 
   // ---- DMA source offsets (elements) of this lane for the pieces its wave issues
   size_t a_src[PA], b_src[PB];
@@ -263,15 +281,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     const float bias_b = p.bias[wcol0 + 32 + l31];
     const float* __restrict__ btab = p.bias_tab;
     // offset (floats) of row r's bias vector inside bias_tab
-    auto tab_off = [&](int row) -> size_t {
-      const int pos = row % p.seq_len;
-      unsigned m = 0;
-      for (int t = 0; t < taps; ++t) {
-        const int pp = pos + t - half_taps;
-        if (pp >= 0 && pp < p.seq_len) m |= 1u << t;
-      }
-      return ((size_t)p.row_group[row] * 32 + m) * p.N + wcol0 + l31;
-    };
+    const uint32_t* rowoff = reinterpret_cast<const uint32_t*>(smem + ROWOFF_OFF);
+    auto tab_off = [&](int row) -> size_t { return (size_t)rowoff[row - m0] + wcol0 + l31; };
     float* __restrict__ res = p.res;
     uint16_t* __restrict__ out0 = reinterpret_cast<uint16_t*>(p.out0);
     uint16_t* __restrict__ out0_lo = p.out0_lo;

@@ -7,7 +7,8 @@ from cube_amd import hip
 split = (sys.argv[1] if len(sys.argv) > 1 else "1") == "1"
 W_ = 14
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 8192 * W_
-Kc, half, taps = 320, 256, 5
+Kc, half, taps = int(os.environ.get('KC', '320')), 256, 5
+use_tab = os.environ.get('TAB', '0') == '1'
 N = 2 * half
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -17,9 +18,11 @@ bias = torch.randn(N, generator=g).to(dev)
 use_res = (sys.argv[3] if len(sys.argv) > 3 else "0") == "1"
 res = torch.zeros((M, half), device=dev) if use_res else None
 out = hip.Pair(torch.zeros((M, Kc), dtype=torch.bfloat16, device=dev), torch.zeros((M, Kc), dtype=torch.bfloat16, device=dev) if split else None)
+tab = torch.randn((7, 32, N), generator=g).to(dev) if use_tab else None
+grp = torch.randint(0, 7, (M,), generator=g).to(torch.int32).to(dev) if use_tab else None
 def run():
     hip.gemm(A, Kc, M, Kc, Wt, N, bias, hip.EPI_GATE, out0=out, ldo0=Kc, col0=0, taps=taps, seq_len=W_, n_valid=half,
-             res=res, ld_res=half if use_res else 0, res_mode=1 if use_res else 0)
+             res=res, ld_res=half if use_res else 0, res_mode=1 if use_res else 0, bias_tab=tab, row_group=grp)
 for _ in range(3): run()
 torch.cuda.synchronize()
 n = 20
