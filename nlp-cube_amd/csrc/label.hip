@@ -1,19 +1,36 @@
 // Label scoring for the decoded heads: logits[d, o] = x1[d]^T W[o] x2[head(d)] + bias[o].
 //
-// One wave owns 32 dependents and a group of labels.  The contraction is run transposed,
-// V^T[q, d] = sum_p W[o][q][p] * x1[d][p]  (v_mfma_f32_32x32x16_bf16: A = 32 rows q of W[o],
-// B = x1 of the 32 dependents), because then every accumulator register of a lane belongs to
-// the lane's own dependent: the second contraction with x2 is a register-local FMA chain plus
-// one half-wave exchange, and the [B*L, n_labels*D] intermediate (343 MB at B=256, L=32) is
-// never materialised.  x1 fragments stay in registers across labels, the gathered x2 rows sit
-// in LDS as fp32 in accumulator order (16-byte conflict-free reads); only W streams
-// (L2-resident).  SPLIT ("bf16x3"): x1 and W are hi/lo bf16 pairs (3 MFMA passes), x2 = hi + lo.
+// One workgroup = 4 waves = 128 dependents and a group of labels; one wave owns 32 dependents.
+// The contraction is run transposed, V^T[q, d] = sum_p W[o][q][p] * x1[d][p]
+// (v_mfma_f32_32x32x16_bf16: A = 32 rows q of W[o], B = x1 of the 32 dependents), because then
+// every accumulator register of a lane belongs to the lane's own dependent: the second
+// contraction with x2 is a register-local FMA chain plus one half-wave exchange, and the
+// [B*L, n_labels*D] intermediate (343 MB at B=256, L=32) is never materialised.
+// x1 fragments stay in registers across labels; the gathered x2 rows sit in LDS (bf16 planes in
+// accumulator order).  W[o] streams through LDS in 32-row chunks by LDS-DMA, double-buffered and
+// SHARED by the four waves (each wave streaming its own copy from L2 was L2-bandwidth bound);
+// chunk rows are padded to an odd number of 16-byte slots so the ds_read_b128 fragment reads are
+// conflict-free.  SPLIT ("bf16x3"): x1 and W are hi/lo bf16 pairs (3 MFMA passes), x2 = hi + lo.
 #include "common.h"
 #include "../../include/cube_hip.h"
 
 namespace {
 
-template <int QT, bool SPLIT>  // D = 32*QT
+__device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int QT, bool SPLIT> struct LabelCfg {
+  static constexpr int D = 32 * QT, KS = D / 16, NPL = SPLIT ? 2 : 1;
+  static constexpr int WROW = D * 2 + 16;                                 // padded chunk row (bytes), odd # of 16-B slots
+  static constexpr int WPLANE = (32 * WROW + 1023) / 1024 * 1024;          // one plane of one 32-row chunk, whole DMA pieces
+  static constexpr int WBUF = NPL * WPLANE;
+  static constexpr int PIECES = WBUF / 1024, PW = (PIECES + 3) / 4;        // 1-KiB pieces per chunk / per wave
+  static constexpr int LDS = 2 * WBUF;
+};
+
+template <int QT, bool SPLIT>
 __global__ __launch_bounds__(256) void label_kernel(const uint16_t* __restrict__ hl, const uint16_t* __restrict__ hl_lo,
                                                     int ld_hl, int col_x2, const uint16_t* __restrict__ wl,
                                                     const uint16_t* __restrict__ wl_lo, const float* __restrict__ bias,
@@ -21,21 +38,47 @@ __global__ __launch_bounds__(256) void label_kernel(const uint16_t* __restrict__
                                                     const int32_t* __restrict__ heads, const int32_t* __restrict__ lens,
                                                     int B, int L, float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int D = 32 * QT;
-  constexpr int KS = D / 16;
-  constexpr int X2_WAVE = QT * 4 * 2 * 32 * 16;  // bytes of one wave's x2 image
+  using C = LabelCfg<QT, SPLIT>;
+  constexpr int D = C::D, KS = C::KS;
   const int T = L + 1;
   const int M = B * L;
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int d0 = (blockIdx.x * 4 + wid) * 32;
-  if (d0 >= M) return;  // whole wave; no block-level barrier is used below
+  const int d0 = (blockIdx.x * 4 + wid) * 32;  // may be >= M for the last waves: they compute on a clamped row, store nothing
   const int d = min(d0 + l31, M - 1);
   const int b = d / L, i = d - b * L;
   const int head = (i < lens[b]) ? heads[(size_t)b * L + i] : 0;
   const size_t x1off = ((size_t)b * T + 1 + i) * ld_hl + lh * 8;
   const size_t x2off = ((size_t)b * T + head) * ld_hl + col_x2 + lh * 4;
+
+  // ---- W chunk DMA: this lane's source offset (elements, inside one 32-row chunk of one plane)
+  // for each piece its wave issues.  LDS byte o of a plane = row o / WROW, 16-byte slot (o % WROW) / 16.
+  int w_src[C::PW];
+#pragma unroll
+  for (int k = 0; k < C::PW; ++k) {
+    const int piece = wid + 4 * k;
+    const int o = (piece % (C::WPLANE / 1024)) * 1024 + lane * 16;
+    const int row = o / C::WROW, slot = (o % C::WROW) >> 4;
+    w_src[k] = (row < 32 && slot < D / 8) ? row * D + slot * 8 : 0;  // padding slots re-read element 0 (never used)
+  }
+  auto issue_chunk = [&](int o, int ct, int buf) {
+    const size_t base = (size_t)o * D * D + (size_t)ct * 32 * D;
+#pragma unroll
+    for (int k = 0; k < C::PW; ++k) {
+      const int piece = wid + 4 * k;
+      if (piece < C::PIECES) {
+        const bool lo_plane = SPLIT && piece >= C::WPLANE / 1024;
+        const uint16_t* src = (lo_plane ? wl_lo : wl) + base + w_src[k];
+        glds16(src, smem + buf * C::WBUF + piece * 1024);
+      }
+    }
+  };
+
+  const int o_begin = blockIdx.y * labels_per_group;
+  const int o_end = min(o_begin + labels_per_group, n_labels);
+  const int n_chunks = (o_end - o_begin) * QT;
+  if (n_chunks > 0) issue_chunk(o_begin, 0, 0);
 
   bf16x8 fx1[SPLIT ? 2 : 1][KS];
 #pragma unroll
@@ -43,55 +86,52 @@ __global__ __launch_bounds__(256) void label_kernel(const uint16_t* __restrict__
     fx1[0][k] = *reinterpret_cast<const bf16x8*>(hl + x1off + k * 16);
     if constexpr (SPLIT) fx1[1][k] = *reinterpret_cast<const bf16x8*>(hl_lo + x1off + k * 16);
   }
-  // x2 of this lane's dependent at q = 32*ct + 8*rq + 4*lh + (0..3) -> LDS [ct][rq][lh][l31] float4
-  float4* x2s = reinterpret_cast<float4*>(smem + wid * X2_WAVE);
+  // x2 of this lane's dependent at q = 32*ct + 8*rq + 4*lh + (0..3), fp32 in registers (one wave per
+  // SIMD: 512 VGPRs are available, x1 fragments + x2 take 2 x 16*QT of them)
+  float x2r[QT][16];
 #pragma unroll
   for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       const uint2 v = *reinterpret_cast<const uint2*>(hl + x2off + ct * 32 + rq * 8);
-      float4 f = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                             __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+      x2r[ct][rq * 4 + 0] = __uint_as_float(v.x << 16);
+      x2r[ct][rq * 4 + 1] = __uint_as_float(v.x & 0xffff0000u);
+      x2r[ct][rq * 4 + 2] = __uint_as_float(v.y << 16);
+      x2r[ct][rq * 4 + 3] = __uint_as_float(v.y & 0xffff0000u);
       if constexpr (SPLIT) {
         const uint2 w = *reinterpret_cast<const uint2*>(hl_lo + x2off + ct * 32 + rq * 8);
-        f.x += __uint_as_float(w.x << 16);
-        f.y += __uint_as_float(w.x & 0xffff0000u);
-        f.z += __uint_as_float(w.y << 16);
-        f.w += __uint_as_float(w.y & 0xffff0000u);
+        x2r[ct][rq * 4 + 0] += __uint_as_float(w.x << 16);
+        x2r[ct][rq * 4 + 1] += __uint_as_float(w.x & 0xffff0000u);
+        x2r[ct][rq * 4 + 2] += __uint_as_float(w.y << 16);
+        x2r[ct][rq * 4 + 3] += __uint_as_float(w.y & 0xffff0000u);
       }
-      x2s[((ct * 4 + rq) * 2 + lh) * 32 + l31] = f;
     }
-  // each lane reads back only what it wrote itself: no barrier needed
+  __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
 
-  const int o_begin = blockIdx.y * labels_per_group;
-  const int o_end = min(o_begin + labels_per_group, n_labels);
+  const int a_rd = l31 * C::WROW + lh * 16;  // fragment read offset inside a chunk plane (k-step adds 32 bytes)
   for (int o = o_begin; o < o_end; ++o) {
-    const size_t woff = (size_t)o * D * D + (size_t)l31 * D + lh * 8;
     float s = 0.f;
 #pragma unroll
     for (int ct = 0; ct < QT; ++ct) {
+      const int n = (o - o_begin) * QT + ct;
+      if (n + 1 < n_chunks) issue_chunk(ct + 1 < QT ? o : o + 1, ct + 1 < QT ? ct + 1 : 0, (n + 1) & 1);
+      const unsigned char* wb = smem + (n & 1) * C::WBUF + a_rd;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const size_t wq = woff + (size_t)ct * 32 * D;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        const bf16x8 fw = *reinterpret_cast<const bf16x8*>(wl + wq + k * 16);
+        const bf16x8 fw = *reinterpret_cast<const bf16x8*>(wb + k * 32);
         if constexpr (SPLIT) {
-          const bf16x8 fwl = *reinterpret_cast<const bf16x8*>(wl_lo + wq + k * 16);
+          const bf16x8 fwl = *reinterpret_cast<const bf16x8*>(wb + C::WPLANE + k * 32);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwl, fx1[0][k], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fx1[1][k], acc, 0, 0, 0);
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fx1[0][k], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const float4 f = x2s[((ct * 4 + rq) * 2 + lh) * 32 + l31];
-        s += acc[rq * 4 + 0] * f.x;
-        s += acc[rq * 4 + 1] * f.y;
-        s += acc[rq * 4 + 2] * f.z;
-        s += acc[rq * 4 + 3] * f.w;
-      }
+      for (int r = 0; r < 16; ++r) s += acc[r] * x2r[ct][r];
+      __syncthreads();  // next chunk landed; everyone is done reading this one before it is overwritten
     }
     s += __shfl_xor(s, 32);
     if (lh == 0 && d0 + l31 < M) logits[(size_t)(d0 + l31) * n_labels + o] = s + bias[o];
@@ -102,8 +142,8 @@ template <int QT>
 int launch_label(bool split, dim3 grid, hipStream_t st, const uint16_t* hl, const uint16_t* hl_lo, int ld_hl, int col_x2,
                  const uint16_t* wl, const uint16_t* wl_lo, const float* bias, int n_labels, int per,
                  const int32_t* heads, const int32_t* lens, int B, int L, float* logits) {
-  const int lds = 4 * QT * 4 * 2 * 32 * 16;
   if (split) {
+    constexpr int lds = LabelCfg<QT, true>::LDS;
     static bool set = false;
     if (!set && lds > 65536) {
       if (hipFuncSetAttribute((const void*)label_kernel<QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -113,6 +153,7 @@ int launch_label(bool split, dim3 grid, hipStream_t st, const uint16_t* hl, cons
     hipLaunchKernelGGL((label_kernel<QT, true>), grid, dim3(256), lds, st, hl, hl_lo, ld_hl, col_x2, wl, wl_lo, bias,
                        n_labels, per, heads, lens, B, L, logits);
   } else {
+    constexpr int lds = LabelCfg<QT, false>::LDS;
     static bool set = false;
     if (!set && lds > 65536) {
       if (hipFuncSetAttribute((const void*)label_kernel<QT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
