@@ -86,9 +86,10 @@ typedef struct cube_gemm_args {
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 
-/* dst[dst_rows ? dst_rows[i] : i, col0 .. col0+width) = table[idx ? idx[i] : 0, 0..width)   (bf16) */
-int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* table, int ld_table,
-                     const int32_t* idx, const int32_t* dst_rows, int n, void* stream);
+/* dst[dst_rows ? dst_rows[i] : i, col0 .. col0+width) = table[idx ? idx[i] : 0, 0..width)   (bf16;
+ * the lo planes, when dst_lo is given, in the same launch)                                   */
+int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, const void* table, const void* table_lo,
+                     int ld_table, const int32_t* idx, const int32_t* dst_rows, int n, void* stream);
 
 /* WordGram tail: out[n, c] = bf16( sum_k weight[k] * sum_{p < len[n]} x_k[n*W + p, c] / max(len[n], 1) )
  * over the n_layers gated-layer outputs x_k (bf16 [N*W, ld_x], hi [+ lo] planes); x_hi / x_lo /

@@ -15,13 +15,13 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 3; }
+extern "C" int cube_abi_version(void) { return 4; }
 
 namespace {
 
-// ---- gather: one wave per row-chunk, 2-byte granularity fallback when not 16-byte alignable
-__global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, int ld_dst, int col0, int width,
-                                                          const uint16_t* table, int ld_table,
+// ---- gather: one wave per row, both planes in one launch; 2-byte fallback when not 16-byte alignable
+__global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, uint16_t* dst_lo, int ld_dst, int col0, int width,
+                                                          const uint16_t* table, const uint16_t* table_lo, int ld_table,
                                                           const int32_t* idx, const int32_t* dst_rows, int n,
                                                           int vec_ok) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -31,13 +31,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* dst, int ld_
     const int src_row = idx ? idx[i] : 0;
     const int dst_row = dst_rows ? dst_rows[i] : i;
     if (dst_row < 0) continue;
-    const uint16_t* s = table + (size_t)src_row * ld_table;
-    uint16_t* d = dst + (size_t)dst_row * ld_dst + col0;
+    const size_t so = (size_t)src_row * ld_table, dof = (size_t)dst_row * ld_dst + col0;
     if (vec_ok) {
-      for (int c = lane * 8; c < width; c += 64 * 8)
-        *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(s + c);
+      for (int c = lane * 8; c < width; c += 64 * 8) {
+        *reinterpret_cast<uint4*>(dst + dof + c) = *reinterpret_cast<const uint4*>(table + so + c);
+        if (dst_lo) *reinterpret_cast<uint4*>(dst_lo + dof + c) = *reinterpret_cast<const uint4*>(table_lo + so + c);
+      }
     } else {
-      for (int c = lane; c < width; c += 64) d[c] = s[c];
+      for (int c = lane; c < width; c += 64) {
+        dst[dof + c] = table[so + c];
+        if (dst_lo) dst_lo[dof + c] = table_lo[so + c];
+      }
     }
   }
 }
@@ -77,6 +81,59 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_
       out[(size_t)n * ld_out + c] = f32_to_bf16(v);
     }
   }
+}
+
+// 8 channels (16 bytes) per thread: the loads of one word row are 512-byte contiguous runs
+__global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
+                                                              int C, uint16_t* out, uint16_t* out_lo, int ld_out) {
+  const int nchunk = C >> 3;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * nchunk) return;
+  const int n = t / nchunk, c = (t - n * nchunk) << 3;
+  const int l = min(max(len[n], 0), W);
+  const float den = (float)max(len[n], 1);
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  const size_t base = (size_t)n * W * ld_x + c;
+  for (int k = 0; k < ly.n; ++k) {
+    float sk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sk[j] = 0.f;
+    const uint16_t* hi = ly.hi[k] + base;
+    const uint16_t* lo = ly.lo[k] ? ly.lo[k] + base : nullptr;
+    for (int q = 0; q < l; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(hi + (size_t)q * ld_x);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sk[2 * j] += __uint_as_float(w[j] << 16);
+        sk[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+      if (lo) {
+        const uint4 u = *reinterpret_cast<const uint4*>(lo + (size_t)q * ld_x);
+        const uint32_t x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sk[2 * j] += __uint_as_float(x[j] << 16);
+          sk[2 * j + 1] += __uint_as_float(x[j] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += ly.weight[k] * sk[j];
+  }
+  uint16_t h[8], lw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = s[j] / den;
+    if (out_lo) split_bf16(v, h[j], lw[j]); else h[j] = f32_to_bf16(v);
+  }
+  const size_t o = (size_t)n * ld_out + c;
+  *reinterpret_cast<uint4*>(out + o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  if (out_lo)
+    *reinterpret_cast<uint4*>(out_lo + o) =
+        make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
 }
 
 __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K,
@@ -122,18 +179,22 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld
 
 }  // namespace
 
-extern "C" int cube_gather_rows(void* dst, int ld_dst, int col0, int width, const void* table, int ld_table,
-                                const int32_t* idx, const int32_t* dst_rows, int n, void* stream) {
+extern "C" int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, const void* table,
+                                const void* table_lo, int ld_table, const int32_t* idx, const int32_t* dst_rows, int n,
+                                void* stream) {
   if (n <= 0 || width <= 0) return CUBE_OK;
   if (!dst || !table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: null pointer");
+  if (dst_lo && !table_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: dst_lo needs table_lo");
   if (col0 < 0 || col0 + width > ld_dst || width > ld_table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: bad columns");
   const int vec_ok = (width % 8 == 0) && (col0 % 8 == 0) && (ld_dst % 8 == 0) && (ld_table % 8 == 0) &&
-                     ((uintptr_t)dst % 16 == 0) && ((uintptr_t)table % 16 == 0);
+                     ((uintptr_t)dst % 16 == 0) && ((uintptr_t)table % 16 == 0) && ((uintptr_t)dst_lo % 16 == 0) &&
+                     ((uintptr_t)table_lo % 16 == 0);
   const int waves_per_block = 4;
   int blocks = (n + waves_per_block - 1) / waves_per_block;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, ld_dst, col0,
-                     width, (const uint16_t*)table, ld_table, idx, dst_rows, n, vec_ok);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, (uint16_t*)dst_lo,
+                     ld_dst, col0, width, (const uint16_t*)table, (const uint16_t*)(dst_lo ? table_lo : nullptr), ld_table, idx,
+                     dst_rows, n, vec_ok);
   CUBE_CHECK_LAUNCH("cube_gather_rows");
   return CUBE_OK;
 }
@@ -152,8 +213,14 @@ extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo
     ly.weight[k] = (k < n_layers && weight) ? weight[k] : 1.0f;
     if (k < n_layers && !ly.hi[k]) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: null layer %d", k);
   }
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ly, ld_x, len, N, W, C,
-                     (uint16_t*)out, (uint16_t*)out_lo, ld_out);
+  bool vec = C % 8 == 0 && ld_x % 8 == 0 && ld_out % 8 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)out_lo % 16 == 0;
+  for (int k = 0; k < n_layers; ++k) vec = vec && (uintptr_t)ly.hi[k] % 16 == 0 && (uintptr_t)ly.lo[k] % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL(masked_mean_vec_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
+                       len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out);
+  else
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ly, ld_x, len, N, W, C,
+                       (uint16_t*)out, (uint16_t*)out_lo, ld_out);
   CUBE_CHECK_LAUNCH("cube_masked_mean");
   return CUBE_OK;
 }

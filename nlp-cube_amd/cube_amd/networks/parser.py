@@ -201,12 +201,10 @@ class _HipNet:
     # ---- the device pipeline ---------------------------------------------------------------
     def _gather(self, dst, ld, col0, width, table, idx, rows, n):
         """embedding lookup / row copy into a concat buffer, every plane (hi[, lo])."""
-        lib, st = hip.load(), hip.stream_handle()
-        for d, t in ((dst.hi, table.hi), (dst.lo, table.lo)):
-            if d is None or t is None:
-                continue
-            hip.check(lib.cube_gather_rows(d.data_ptr(), ld, col0, width, t.data_ptr(), t.shape[1], hip.ptr(idx),
-                                           hip.ptr(rows), n, st), "cube_gather_rows")
+        lo = dst.lo is not None and table.lo is not None
+        hip.check(hip.load().cube_gather_rows(dst.hi.data_ptr(), hip.ptr(dst.lo) if lo else None, ld, col0, width,
+                                              table.hi.data_ptr(), hip.ptr(table.lo) if lo else None, table.hi.shape[1],
+                                              hip.ptr(idx), hip.ptr(rows), n, hip.stream_handle()), "cube_gather_rows")
 
     @staticmethod
     def _zero(pair, numel):

@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 3
+        return 4
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -107,7 +107,7 @@ class TraceLib:
                 self._need("gemm " + nm, p, 2 * ((M - 1) * ld + c + nv), 2)
         return 0
 
-    def cube_gather_rows(self, dst, ld_dst, col0, width, table, ld_table, idx, dst_rows, n, stream):
+    def cube_gather_rows(self, dst, dst_lo, ld_dst, col0, width, table, table_lo, ld_table, idx, dst_rows, n, stream):
         self.calls.append(("gather", n, width))
         if n <= 0 or width <= 0:
             return 0
@@ -119,8 +119,10 @@ class TraceLib:
             dmax = int(dr.max())
         else:
             dmax = n - 1
-        self._need("gather table", table, 2 * (src_max * ld_table + width), 2)
-        self._need("gather dst", dst, 2 * (dmax * ld_dst + col0 + width), 2)
+        assert dst_lo is None or table_lo is not None
+        for nm, t, d in (("", table, dst), ("_lo", table_lo if dst_lo else None, dst_lo)):
+            self._need("gather table" + nm, t, 2 * (src_max * ld_table + width), 2)
+            self._need("gather dst" + nm, d, 2 * (dmax * ld_dst + col0 + width), 2)
         return 0
 
     def cube_masked_mean(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, stream):
