@@ -73,6 +73,23 @@ enum {
  *   bias_tab[(row_group[r] * 32 + tapmask(r)) * N + n],   tapmask bit t = tap t is inside,
  * computed at load time (bias + sum over inside taps of W_lang[n, tap, :] . emb[group]), and the
  * GEMM runs over the remaining channels only.  bias_tab f32 [n_groups, 32, N]; row_group i32 [M]. */
+
+/* Ragged sequence groups (CUBE_EPI_GATE without res / rowmap).  The rows of A are n groups; group
+ * g owns rows [row0_in, row0_in + n_rows) as sequences of seq_in rows (n_rows % seq_in == 0; its
+ * sequences are words word0, word0 + 1, ... for row_group, which is then indexed per WORD).
+ * All seq_in positions are computed with Conv1d zero padding at both ends of the sequence; the
+ * first seq_out <= seq_in positions of sequence j are written to row row0_out + j*seq_out + pos of
+ * the outputs, the others are dropped.  This is how the character CNN skips the padded tail of
+ * short words: layer l only needs positions < len + 2*(layers - 1 - l) (modules.py:462-481: the
+ * masked mean reads positions < len of every layer, each Conv1d(k=5) looks 2 positions ahead).
+ * Row tiles never straddle groups.  A HOST struct, read at launch.                              */
+#define CUBE_MAX_CONV_GROUPS 32
+typedef struct cube_conv_groups {
+  int n;
+  int row0_in[CUBE_MAX_CONV_GROUPS], n_rows[CUBE_MAX_CONV_GROUPS], seq_in[CUBE_MAX_CONV_GROUPS];
+  int row0_out[CUBE_MAX_CONV_GROUPS], seq_out[CUBE_MAX_CONV_GROUPS], word0[CUBE_MAX_CONV_GROUPS];
+} cube_conv_groups;
+
 typedef struct cube_gemm_args {
   const void* A; const void* A_lo; int lda; int M; int seq_len; int taps; int Kc;
   const void* W; const void* W_lo; int N; const float* bias;
@@ -83,6 +100,7 @@ typedef struct cube_gemm_args {
   void* out1; void* out1_lo; int ldo1; int col1;
   void* out2; void* out2_lo; int ldo2; int col2;
   const float* bias_tab; const int32_t* row_group; int n_groups;
+  const cube_conv_groups* groups;   /* optional, host memory */
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 
@@ -94,11 +112,13 @@ int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, c
 /* WordGram tail: out[n, c] = bf16( sum_k weight[k] * sum_{p < len[n]} x_k[n*W + p, c] / max(len[n], 1) )
  * over the n_layers gated-layer outputs x_k (bf16 [N*W, ld_x], hi [+ lo] planes); x_hi / x_lo /
  * weight are HOST arrays of n_layers entries (x_lo may be NULL).  With weight = 1,..,1,2 this is
- * the reference's (x + res) masked mean, res = sum of all layers, x = the last one.              */
+ * the reference's (x + res) masked mean, res = sum of all layers, x = the last one.
+ * word_rows (optional, device i32 [n_layers, N]): first row of word n in layer k's buffer when the
+ * layers are laid out in ragged sequence groups (cube_conv_groups); NULL = row n*W in every layer. */
 #define CUBE_MAX_MEAN_LAYERS 8
 int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                      int ld_x, const int32_t* len, int N, int W, int C,
-                     void* out, void* out_lo, int ld_out, void* stream);
+                     void* out, void* out_lo, int ld_out, const int32_t* word_rows, void* stream);
 
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
  * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);

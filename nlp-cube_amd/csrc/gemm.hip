@@ -33,10 +33,10 @@ struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
 constexpr int MAX_TAPS = 5;
 // slab rows allocated in LDS: tile rows + halo, rounded to the 16 rows one LDS-DMA piece fills
 template <class C> constexpr int slab_rows() { return (C::BM + MAX_TAPS - 1 + 15) / 16 * 16; }
-// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row][bias-table offset per tile row];
-// every operand buffer holds NP planes
+// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row][per tile row: bias-table offset, output
+// row, tap mask]; every operand buffer holds NP planes
 template <class C, bool SPLIT> constexpr int lds_bytes() {
-  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + C::BM * 4;
+  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + 3 * C::BM * 4;
 }
 
 struct GemmParams {
@@ -52,6 +52,11 @@ struct GemmParams {
   int vec_out;               // gate epilogue without residual: 16-byte row-contiguous stores are legal
   const float* bias_tab; const int32_t* row_group;  // row-dependent bias (broadcast channels folded in)
 };
+
+// Ragged sequence groups (host struct cube_conv_groups passed by value): group g owns input rows
+// [row0_in, row0_in + n_rows) as sequences of seq_in rows, writes the first seq_out positions of
+// each sequence to rows row0_out + j*seq_out + pos, and its sequences are words word0, word0+1, ...
+typedef cube_conv_groups ConvGroups;
 
 __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t idx, float v) {
   if (lo) {
@@ -80,7 +85,7 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 // neighbouring sequence (Conv1d zero padding) are redirected, per lane, to a zero row in LDS.
 // Both operands go global -> LDS by LDS-DMA (no staging registers, no ds_write), one k-step ahead.
 template <int EPI, bool SPLIT, class C>
-__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int NW = C::WM * C::WN;
@@ -105,7 +110,19 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int mt = (slot / p.n_tiles) * 8 + xcd;
   if (mt >= p.m_tiles) return;  // whole block: before any barrier
-  const int m0 = mt * BM;
+  // the row tile's sequence group (one implicit group = the whole matrix when cg.n == 0)
+  int row_lo = 0, row_hi = p.M, seq = p.seq_len, seq_out = p.seq_len, row0_out = 0, word0 = 0, m0 = mt * BM;
+  if (cg.n > 0) {
+    int g = 0, t0 = 0;
+    for (; g < cg.n - 1; ++g) {
+      const int nt = (cg.n_rows[g] + BM - 1) / BM;
+      if (mt < t0 + nt) break;
+      t0 += nt;
+    }
+    row_lo = cg.row0_in[g]; row_hi = row_lo + cg.n_rows[g]; seq = cg.seq_in[g]; seq_out = cg.seq_out[g];
+    row0_out = cg.row0_out[g]; word0 = cg.word0[g];
+    m0 = row_lo + (mt - t0) * BM;
+  }
   const int n0 = (slot % p.n_tiles) * BN;
   const int taps = p.taps;
   const int half_taps = taps >> 1;
@@ -114,22 +131,27 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int ktot = taps * p.Kc;
 
   if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
-  // row-dependent bias: offset of each tile row's bias vector (one modulo per row, done once here;
-  // visible to the epilogue through the barriers of the main loop)
-  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB;
-  if (p.bias_tab && tid < BM) {
+  // per tile row, computed once (one division per row): which taps fall inside the row's sequence,
+  // where its output goes (-1: nowhere) and the offset of its bias vector in bias_tab.  Read after
+  // the first barrier below.
+  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB, OROW_OFF = ROWOFF_OFF + BM * 4, MASK_OFF = OROW_OFF + BM * 4;
+  if (tid < BM) {
     const int row = m0 + tid;
-    unsigned off = 0;
-    if (row < p.M) {
-      const int pos = row % p.seq_len;
-      unsigned m = 0;
+    unsigned off = 0, m = 0;
+    int orow = -1;
+    if (row < row_hi) {
+      const int rel = row - row_lo;
+      const int j = rel / seq, pos = rel - j * seq;
       for (int t = 0; t < taps; ++t) {
         const int pp = pos + t - half_taps;
-        if (pp >= 0 && pp < p.seq_len) m |= 1u << t;
+        if (pp >= 0 && pp < seq) m |= 1u << t;
       }
-      off = ((unsigned)p.row_group[row] * 32u + m) * (unsigned)p.N;
+      if (pos < seq_out) orow = row0_out + j * seq_out + pos;
+      if (p.bias_tab) off = ((unsigned)p.row_group[cg.n > 0 ? word0 + j : row] * 32u + m) * (unsigned)p.N;
     }
     reinterpret_cast<uint32_t*>(smem + ROWOFF_OFF)[tid] = off;
+    reinterpret_cast<int32_t*>(smem + OROW_OFF)[tid] = orow;
+    reinterpret_cast<uint32_t*>(smem + MASK_OFF)[tid] = m;
   }
 
   // ---- DMA source offsets (elements) of this lane for the pieces its wave issues
@@ -155,18 +177,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   int a_row[TM];
   unsigned vmask[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int lr = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
-    a_row[i] = lr;
-    const int r = m0 + lr;
-    const int pos = r % p.seq_len;
-    unsigned m = 0;
-    for (int t = 0; t < taps; ++t) {
-      const int pp = pos + t - half_taps;
-      if (r < p.M && pp >= 0 && pp < p.seq_len) m |= 1u << t;
-    }
-    vmask[i] = m;
-  }
+  for (int i = 0; i < TM; ++i) a_row[i] = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
   int b_rd[TN][2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -202,6 +213,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   ISSUE_A(0, 0)
   ISSUE_B(0, 0)
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) vmask[i] = reinterpret_cast<const uint32_t*>(smem + MASK_OFF)[a_row[i]];
 
   int kc = 0, tap = 0;
   for (int s = 0; s < nk; ++s) {
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     const float* __restrict__ btab = p.bias_tab;
     // offset (floats) of row r's bias vector inside bias_tab
     const uint32_t* rowoff = reinterpret_cast<const uint32_t*>(smem + ROWOFF_OFF);
+    const int32_t* orow_lds = reinterpret_cast<const int32_t*>(smem + OROW_OFF);
     auto tab_off = [&](int row) -> size_t { return (size_t)rowoff[row - m0] + wcol0 + l31; };
     float* __restrict__ res = p.res;
     uint16_t* __restrict__ out0 = reinterpret_cast<uint16_t*>(p.out0);
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (btab && row < p.M) {
+          if (btab) {
             const size_t o = tab_off(row);
             ba[r] = btab[o];
             bb[r] = btab[o + 32];
@@ -325,8 +339,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int lr = srow + 16 * hh;
-          const int row = wrow0 + i * 32 + lr;
-          if (row < p.M && cbase < p.n_valid) {
+          const int row = orow_lds[wrow0 - m0 + i * 32 + lr];  // output row (ragged groups re-lay rows), -1 = none
+          if (row >= 0 && cbase < p.n_valid) {
             const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;
             *reinterpret_cast<uint4*>(out0 + o) = *reinterpret_cast<const uint4*>(stg + lr * SROW + schunk * 16);
             if constexpr (SPLIT)
@@ -345,8 +359,9 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        rv[r] = (res && res_mode != 0 && ch_ok && row < p.M) ? res[(size_t)row * p.ld_res + ch] : 0.f;
-        if (btab && row < p.M) {
+        const int orow = orow_lds[row - m0];
+        rv[r] = (res && res_mode != 0 && ch_ok && orow >= 0) ? res[(size_t)orow * p.ld_res + ch] : 0.f;
+        if (btab) {
           const size_t o = tab_off(row);
           ba[r] = btab[o];
           bb[r] = btab[o + 32];
@@ -357,8 +372,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M && ch_ok) {
+        const int row = orow_lds[wrow0 - m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        if (row >= 0 && ch_ok) {
           const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
           if (out0) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
           if (!res) continue;  // plain gated layer: no residual stream
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 }
 
 template <int EPI, bool SPLIT, class C>
-int launch_cfg(GemmParams p, hipStream_t st) {
+int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
@@ -413,17 +428,21 @@ int launch_cfg(GemmParams p, hipStream_t st) {
   }
   p.n_tiles = p.N / C::BN;
   p.m_tiles = (p.M + C::BM - 1) / C::BM;
+  if (cg.n > 0) {
+    p.m_tiles = 0;
+    for (int g = 0; g < cg.n; ++g) p.m_tiles += (cg.n_rows[g] + C::BM - 1) / C::BM;
+  }
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
-  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
   return CUBE_OK;
 }
 
 template <int EPI>
-int launch(const GemmParams& p, hipStream_t st) {
+int launch(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
   // the big tile needs enough row tiles to fill the 256 CUs
   const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
-  if (p.A_lo) return big ? launch_cfg<EPI, true, CfgBig>(p, st) : launch_cfg<EPI, true, CfgSmall>(p, st);
-  return big ? launch_cfg<EPI, false, CfgBig>(p, st) : launch_cfg<EPI, false, CfgSmall>(p, st);
+  if (p.A_lo) return big ? launch_cfg<EPI, true, CfgBig>(p, cg, st) : launch_cfg<EPI, true, CfgSmall>(p, cg, st);
+  return big ? launch_cfg<EPI, false, CfgBig>(p, cg, st) : launch_cfg<EPI, false, CfgSmall>(p, cg, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -442,7 +461,21 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   if (a->lda < a->Kc || a->lda % 8) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
   if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->A_lo) || !aligned16(a->W_lo))
     CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: operands must be 16-byte aligned");
-  const int seq = a->taps == 1 ? a->M : a->seq_len;
+  ConvGroups cg;
+  cg.n = 0;
+  if (a->groups) {
+    cg = *a->groups;
+    if (cg.n <= 0 || cg.n > CUBE_MAX_CONV_GROUPS) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: %d sequence groups (1..%d)", cg.n, CUBE_MAX_CONV_GROUPS);
+    if (a->epilogue != CUBE_EPI_GATE || a->res || a->rowmap)
+      CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: sequence groups need the gate epilogue without residual stream / rowmap");
+    for (int g = 0; g < cg.n; ++g) {
+      if (cg.seq_in[g] <= 0 || cg.n_rows[g] <= 0 || cg.n_rows[g] % cg.seq_in[g] || cg.seq_out[g] <= 0 ||
+          cg.seq_out[g] > cg.seq_in[g] || cg.row0_in[g] < 0 || cg.row0_in[g] + cg.n_rows[g] > a->M || cg.row0_out[g] < 0 ||
+          cg.word0[g] < 0)
+        CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad sequence group %d", g);
+    }
+  }
+  const int seq = (a->taps == 1 || a->groups) ? a->M : a->seq_len;
   if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: M=%d not a multiple of seq_len=%d", a->M, seq);
   GemmParams p;
   p.vec_out = 0; p.m_tiles = p.n_tiles = 0;
@@ -466,15 +499,15 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   switch (a->epilogue) {
     case CUBE_EPI_F32:
       if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
-      rc = launch<CUBE_EPI_F32>(p, st);
+      rc = launch<CUBE_EPI_F32>(p, cg, st);
       break;
     case CUBE_EPI_BF16:
     case CUBE_EPI_BF16_TANH:
     case CUBE_EPI_BF16_RELU:
       if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
-      if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, st);
-      else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, st);
-      else rc = launch<CUBE_EPI_BF16_RELU>(p, st);
+      if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, cg, st);
+      else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, cg, st);
+      else rc = launch<CUBE_EPI_BF16_RELU>(p, cg, st);
       break;
     case CUBE_EPI_GATE: {
       const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile
@@ -490,7 +523,7 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
       if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
       p.vec_out = !a->res && a->out0 && half % 8 == 0 && a->ldo0 % 8 == 0 && a->col0 % 8 == 0 && aligned16(a->out0) &&
                   aligned16(a->out0_lo);
-      rc = launch<CUBE_EPI_GATE>(p, st);
+      rc = launch<CUBE_EPI_GATE>(p, cg, st);
       break;
     }
     default:

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 4; }
+extern "C" int cube_abi_version(void) { return 5; }
 
 namespace {
 
@@ -54,7 +54,8 @@ struct MeanLayers {
   int n;
 };
 __global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
-                                                          int C, uint16_t* out, uint16_t* out_lo, int ld_out) {
+                                                          int C, uint16_t* out, uint16_t* out_lo, int ld_out,
+                                                          const int32_t* word_rows) {
   const int n = blockIdx.x;
   if (n >= N) return;
   const int l = min(max(len[n], 0), W);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < ly.n; ++k) {
-      const size_t base = (size_t)n * W * ld_x + c;
+      const size_t base = (size_t)(word_rows ? word_rows[(size_t)k * N + n] : n * W) * ld_x + c;
       float sk = 0.f;
       for (int q = 0; q < l; ++q) {
         float v = bf16_to_f32(ly.hi[k][base + (size_t)q * ld_x]);
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(MeanLayers ly, int ld_
 
 // 8 channels (16 bytes) per thread: the loads of one word row are 512-byte contiguous runs
 __global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
-                                                              int C, uint16_t* out, uint16_t* out_lo, int ld_out) {
+                                                              int C, uint16_t* out, uint16_t* out_lo, int ld_out,
+                                                              const int32_t* word_rows) {
   const int nchunk = C >> 3;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * nchunk) return;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int
   float s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
-  const size_t base = (size_t)n * W * ld_x + c;
   for (int k = 0; k < ly.n; ++k) {
+    const size_t base = (size_t)(word_rows ? word_rows[(size_t)k * N + n] : n * W) * ld_x + c;
     float sk[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) sk[j] = 0.f;
@@ -201,7 +203,7 @@ extern "C" int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, i
 
 extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                                 int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
-                                void* stream) {
+                                const int32_t* word_rows, void* stream) {
   if (N <= 0) return CUBE_OK;
   if (!x_hi || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
   if (n_layers <= 0 || n_layers > CUBE_MAX_MEAN_LAYERS) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: n_layers=%d (max %d)", n_layers, CUBE_MAX_MEAN_LAYERS);
@@ -217,10 +219,10 @@ extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo
   for (int k = 0; k < n_layers; ++k) vec = vec && (uintptr_t)ly.hi[k] % 16 == 0 && (uintptr_t)ly.lo[k] % 16 == 0;
   if (vec)
     hipLaunchKernelGGL(masked_mean_vec_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
-                       len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out);
+                       len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
   else
     hipLaunchKernelGGL(masked_mean_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ly, ld_x, len, N, W, C,
-                       (uint16_t*)out, (uint16_t*)out_lo, ld_out);
+                       (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
   CUBE_CHECK_LAUNCH("cube_masked_mean");
   return CUBE_OK;
 }

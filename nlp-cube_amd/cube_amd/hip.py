@@ -10,9 +10,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 4  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 5  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+
+MAX_CONV_GROUPS = 32
+
+
+class ConvGroups(ctypes.Structure):
+    """cube_conv_groups (include/cube_hip.h): ragged sequence groups of one conv layer, host memory."""
+    _fields_ = [("n", c_int)] + [(k, c_int * MAX_CONV_GROUPS) for k in
+                                 ("row0_in", "n_rows", "seq_in", "row0_out", "seq_out", "word0")]
 
 
 class GemmArgs(ctypes.Structure):
@@ -27,6 +36,7 @@ class GemmArgs(ctypes.Structure):
         ("out1", c_void_p), ("out1_lo", c_void_p), ("ldo1", c_int), ("col1", c_int),
         ("out2", c_void_p), ("out2_lo", c_void_p), ("ldo2", c_int), ("col2", c_int),
         ("bias_tab", c_void_p), ("row_group", c_void_p), ("n_groups", c_int),
+        ("groups", ctypes.POINTER(ConvGroups)),
     ]
 
 
@@ -61,7 +71,7 @@ SIGNATURES = {
     "cube_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),
     "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
-                                 c_void_p, c_int, c_void_p]),
+                                 c_void_p, c_int, c_void_p, c_void_p]),
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -132,7 +142,7 @@ def _planes(x, col=0):
 
 def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
          rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
-         a_col=0, bias_tab=None, row_group=None, stream=None):
+         a_col=0, bias_tab=None, row_group=None, groups=None, stream=None):
     """A, W, out0 (bf16 epilogues), out1, out2: `Pair`s; out0 of CUBE_EPI_F32: an fp32 tensor.
     bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements)."""
     a = GemmArgs()
@@ -156,14 +166,17 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     a.ldo2, a.col2 = ldo2, col2
     a.bias_tab, a.row_group = ptr(bias_tab), ptr(row_group)
     a.n_groups = 0 if bias_tab is None else bias_tab.shape[0]
+    if groups is not None:
+        a.groups = ctypes.pointer(groups)
     check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")
 
 
-def masked_mean(layers, weights, ld_x, word_len, N, W, C, out, ld_out, stream=None):
-    """layers: list of Pair [N*W, ld_x]; out: Pair [N, ld_out]."""
+def masked_mean(layers, weights, ld_x, word_len, N, W, C, out, ld_out, word_rows=None, stream=None):
+    """layers: list of Pair [N*W, ld_x] (or ragged, with word_rows i32 [n_layers, N]); out: Pair [N, ld_out]."""
     n = len(layers)
     his = (c_void_p * n)(*[l.hi.data_ptr() for l in layers])
     los = (c_void_p * n)(*[l.lo.data_ptr() for l in layers]) if layers[0].lo is not None else None
     ws = (ctypes.c_float * n)(*weights)
     check(load().cube_masked_mean(his, los, ws, n, ld_x, word_len.data_ptr(), N, W, C, out.hi.data_ptr(), ptr(out.lo),
-                                  ld_out, stream if stream is not None else stream_handle()), "cube_masked_mean")
+                                  ld_out, ptr(word_rows), stream if stream is not None else stream_handle()),
+          "cube_masked_mean")

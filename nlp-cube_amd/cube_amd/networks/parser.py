@@ -173,10 +173,15 @@ class _HipNet:
         si = np.arange(N) - np.repeat(np.cumsum(sl) - sl, sl)
         word_idx = np.zeros((B, T), dtype=np.int32)
         word_idx[:, root:] = x_sent
+        ch = self._char_layout(X["x_word_len"].cpu().numpy().astype(np.int64), W)
+        order = ch["order"]
+        x_case = X["x_word_case"].cpu().numpy()
+        char_idx = np.concatenate([x_word[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
+        case_idx = np.concatenate([x_case[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
         parts = [
-            x_word.reshape(-1), X["x_word_case"].cpu().numpy().reshape(-1),
-            np.repeat(X["x_lang_word"].cpu().numpy(), W), X["x_word_len"].cpu().numpy(),
-            sb * T + si + root, word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
+            char_idx, case_idx, X["x_lang_word"].cpu().numpy()[order], X["x_word_len"].cpu().numpy()[order],
+            (sb * T + si + root)[order], word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
+            ch["word_rows"].reshape(-1),
         ]
         sizes = [p.size for p in parts]
         offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
@@ -184,8 +189,8 @@ class _HipNet:
         for p, o, s in zip(parts, offs[:-1], sizes):
             packed[o:o + s] = p
         ints = torch.from_numpy(packed).to(dev, non_blocking=True)
-        names = ("char_idx", "case_idx", "lang_char", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
-                 "lens")
+        names = ("char_idx", "case_idx", "lang_word", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
+                 "lens", "word_rows")
         bt = {n: ints[o:o + s] for n, o, s in zip(names, offs[:-1], sizes)}
         embs = []
         for k, e in enumerate(X["x_word_embeddings"]):
@@ -193,10 +198,41 @@ class _HipNet:
             pad = torch.zeros((B * L, ek["Epad"]), dtype=torch.float32)
             pad[torch.from_numpy(sb * L + si), :ek["E"]] = e.cpu().to(torch.float32)
             embs.append(hip.Pair.split(pad, with_lo=self._split).to(dev))
-        bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs)
+        bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs, conv_groups=ch["groups"], char_rows=ch["rows"])
         if "y_upos" in X:
             bt["y_upos"] = X["y_upos"].to(dev).to(torch.int32).contiguous()
         return bt
+
+    def _char_layout(self, word_len, W):
+        """Ragged layouts of the character CNN.  The masked mean (modules.py:479-483) reads positions
+        < len of every gated layer and each Conv1d(k=5) looks two positions ahead, so layer l (of n)
+        only has to produce positions < len + 2*(n-1-l) of a word, from positions < len + 2*(n-l) of
+        its input — the padded tail of short words is never computed.  Words are grouped by length
+        (<= 32 groups); layout k (k = 0: embeddings, k = l+1: output of layer l) keeps
+        min(W, len_g + 2*(n-k)) rows per word of group g, groups one after the other.
+        -> order (sorted word -> original word), per-layer cube_conv_groups, rows per layout,
+        word_rows [n, N] (first row of sorted word i in the output of layer l), gather list."""
+        n = self._config.char_layers
+        key = np.minimum(np.maximum(word_len, 1), hip.MAX_CONV_GROUPS - 1)
+        order = np.argsort(key, kind="stable")
+        ks, starts, counts = np.unique(key[order], return_index=True, return_counts=True)
+        gmax = np.array([max(int(word_len[order[s:s + c]].max()), 1) for s, c in zip(starts, counts)])
+        seq = np.minimum(W, gmax[None, :] + 2 * (n - np.arange(n + 1))[:, None])       # [n+1 layouts, G]
+        rows_g = seq * counts[None, :]
+        row0 = np.concatenate([np.zeros((n + 1, 1), dtype=np.int64), np.cumsum(rows_g, axis=1)[:, :-1]], axis=1)
+        groups = []
+        for l in range(n):
+            cg = hip.ConvGroups()
+            cg.n = len(ks)
+            for g in range(len(ks)):
+                cg.row0_in[g], cg.n_rows[g], cg.seq_in[g] = int(row0[l, g]), int(rows_g[l, g]), int(seq[l, g])
+                cg.row0_out[g], cg.seq_out[g], cg.word0[g] = int(row0[l + 1, g]), int(seq[l + 1, g]), int(starts[g])
+            groups.append(cg)
+        j = np.arange(len(word_len)) - np.repeat(starts, counts)                          # index inside the group
+        word_rows = np.stack([np.repeat(row0[l + 1], counts) + j * np.repeat(seq[l + 1], counts) for l in range(n)])
+        gather = [(int(s), int(s + c), int(q)) for s, c, q in zip(starts, counts, seq[0])]
+        return dict(order=order, groups=groups, rows=[int(r) for r in rows_g.sum(axis=1)],
+                    word_rows=word_rows.astype(np.int32), gather=gather)
 
     # ---- the device pipeline ---------------------------------------------------------------
     def _gather(self, dst, ld, col0, width, table, idx, rows, n):
@@ -226,28 +262,30 @@ class _HipNet:
         gather = self._gather
         lo = hip.ptr  # lo-plane pointer helper: hip.ptr(pair.lo) is None in single-pass mode
         B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
-        NW, BT, BL = N * W, B * T, B * L
+        BT, BL = B * T, B * L
         ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
 
-        # ---- character level
-        xc0 = buf.get("xc0", NW, lay.xc0_w)
-        gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, NW)
-        gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, NW)
+        # ---- character level, in ragged per-length layouts (`_char_layout`)
+        rows = bt["char_rows"]
+        xc0 = buf.get("xc0", rows[0], lay.xc0_w)
+        gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, rows[0])
+        gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, rows[0])
         nchar = len(pk["char_convs"])
         # every gated layer keeps its own output g_l: the next layer reads it, and the masked mean
         # sums them (no fp32 residual stream through HBM at N*W rows).  The language channels are
         # not materialised: they enter through the per-(language, tap mask) bias table.
-        gl = [buf.get("xc_g%d" % l, NW, lay.xc_w) for l in range(nchar)]
+        gl = [buf.get("xc_g%d" % l, rows[l + 1], lay.xc_w) for l in range(nchar)]
         src, src_ld = xc0, lay.xc0_w
         for l, cv in enumerate(pk["char_convs"]):
             with self._timed("char_conv" if l > 0 else "char_conv0"):
-                hip.gemm(src, src_ld, NW, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
+                hip.gemm(src, src_ld, rows[l], cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
                          ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"],
-                         bias_tab=cv["bias_tab"], row_group=bt["lang_char"], stream=st)
+                         bias_tab=cv["bias_tab"], row_group=bt["lang_word"], groups=bt["conv_groups"][l], stream=st)
             src, src_ld = gl[l], lay.xc_w
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
-        hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w, stream=st)
+        hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w,
+                        word_rows=bt["word_rows"], stream=st)
         # ---- word level input XW0 = [word | char | lang | ext] (+ root row = _r_emb for the parser)
         xw0 = buf.get("xw0", BT, lay.xw0_w)
         self._zero(xw0, BT * lay.xw0_w)

@@ -72,14 +72,14 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 4
+        return 5
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
         self.calls.append(("gemm", a.epilogue, a.M, a.N, a.Kc, a.taps))
         M, N, Kc, taps = a.M, a.N, a.Kc, a.taps
         assert Kc % 32 == 0 and N % 128 == 0 and a.lda >= Kc and a.lda % 8 == 0
-        assert taps == 1 or (a.seq_len > 0 and M % a.seq_len == 0)
+        assert taps == 1 or a.groups or (a.seq_len > 0 and M % a.seq_len == 0)
         for nm, p in (("A", a.A), ("A_lo", a.A_lo)):
             self._need("gemm " + nm, p, 2 * ((M - 1) * a.lda + Kc), 16)
         for nm, p in (("W", a.W), ("W_lo", a.W_lo)):
@@ -87,12 +87,23 @@ class TraceLib:
         gate = a.epilogue == hip.EPI_GATE
         nv = a.n_valid if a.n_valid > 0 else (N // 2 if gate else N)
         self._need("gemm bias", a.bias, 4 * (N if gate else nv), 4)
+        out_rows, n_words = M, M
+        if a.groups:
+            cg = a.groups.contents
+            assert gate and not a.res and not a.rowmap and 1 <= cg.n <= 32
+            out_rows = n_words = 0
+            for g in range(cg.n):
+                assert cg.seq_in[g] > 0 and cg.n_rows[g] % cg.seq_in[g] == 0 and 0 < cg.seq_out[g] <= cg.seq_in[g]
+                assert cg.row0_in[g] >= 0 and cg.row0_in[g] + cg.n_rows[g] <= M
+                nw = cg.n_rows[g] // cg.seq_in[g]
+                out_rows = max(out_rows, cg.row0_out[g] + nw * cg.seq_out[g])
+                n_words = max(n_words, cg.word0[g] + nw)
         if a.bias_tab:
             assert gate and a.row_group and taps <= 5 and a.n_groups > 0
-            grp = self._ints("gemm row_group", a.row_group, M)
+            grp = self._ints("gemm row_group", a.row_group, n_words)
             assert grp.min() >= 0 and grp.max() < a.n_groups
             self._need("gemm bias_tab", a.bias_tab, 4 * a.n_groups * 32 * N, 4)
-        rows = M
+        rows = out_rows
         if a.rowmap:
             rm = self._ints("gemm rowmap", a.rowmap, M)
             rows = int(rm.max()) + 1
@@ -125,14 +136,17 @@ class TraceLib:
             self._need("gather dst" + nm, d, 2 * (dmax * ld_dst + col0 + width), 2)
         return 0
 
-    def cube_masked_mean(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, stream):
+    def cube_masked_mean(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
+                         stream):
         self.calls.append(("masked_mean", n_layers, N, W, C))
         assert 0 < n_layers <= 8 and C <= ld_x and C <= ld_out
+        lens = np.clip(self._ints("masked_mean len", length, N), 0, W)
+        wr = self._ints("masked_mean word_rows", word_rows, n_layers * N).reshape(n_layers, N) if word_rows else None
         for k in range(n_layers):
-            self._need("masked_mean x_hi[%d]" % k, x_hi[k], 2 * ((N * W - 1) * ld_x + C), 2)
+            last = int((wr[k] + np.maximum(lens, 1) - 1).max()) if wr is not None else N * W - 1
+            self._need("masked_mean x_hi[%d]" % k, x_hi[k], 2 * (last * ld_x + C), 2)
             if x_lo is not None:
-                self._need("masked_mean x_lo[%d]" % k, x_lo[k], 2 * ((N * W - 1) * ld_x + C), 2)
-        self._need("masked_mean len", length, 4 * N, 4)
+                self._need("masked_mean x_lo[%d]" % k, x_lo[k], 2 * (last * ld_x + C), 2)
         for nm, p in (("out", out), ("out_lo", out_lo)):
             self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
         return 0
