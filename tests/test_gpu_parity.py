@@ -146,6 +146,57 @@ def test_gemm_gate_epilogue_and_rowmap(dev, split, M, seq, Kc, half):
     assert (out.cpu().numpy()[1::2] == 0).all()
 
 
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("big", [False, True])
+def test_gemm_ragged_groups_and_bias_table(dev, split, big):
+    """Gated conv over ragged sequence groups (cube_conv_groups) with the broadcast channels
+    folded into the (group, tap mask) bias table, against torch.conv1d per group in float64 on
+    the FULL input (broadcast channels concatenated, as the reference does)."""
+    from cube_amd import hip
+    from cube_amd.networks import packing
+    g = torch.Generator().manual_seed(9)
+    Kc, nb, half, n_lang = 64, 16, 128 if big else 48, 4
+    # (words, seq_in, seq_out)
+    spec = [(3, 1, 1), (5, 3, 1), (700 if big else 7, 7, 5), (4000 if big else 9, 14, 14), (4, 9, 8)]
+    w = torch.randn((2 * half, Kc + nb, 5), generator=g) / np.sqrt(5 * (Kc + nb))
+    sd = {"c.0.conv.weight": w, "c.0.conv.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.weight": torch.rand(2 * half, generator=g) + 0.5, "c.1.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.running_mean": torch.randn(2 * half, generator=g) * 0.1, "c.1.running_var": torch.rand(2 * half, generator=g) + 0.5}
+    table = torch.randn((n_lang, nb), generator=g)
+    pk = packing.pack_gated_conv(sd, "c", np.arange(Kc), bcast=(Kc + np.arange(nb), table))
+    s = sd["c.1.weight"] / torch.sqrt(sd["c.1.running_var"] + 1e-5)
+    wf = w * s[:, None, None]
+    bf = (sd["c.0.conv.bias"] - sd["c.1.running_mean"]) * s + sd["c.1.bias"]
+    rnd = (lambda t: t) if split else _bf16_round
+    cg = hip.ConvGroups()
+    cg.n = len(spec)
+    rin = rout = wd = 0
+    for k, (nw, si, so) in enumerate(spec):
+        cg.row0_in[k], cg.n_rows[k], cg.seq_in[k], cg.row0_out[k], cg.seq_out[k], cg.word0[k] = rin, nw * si, si, rout, so, wd
+        rin, rout, wd = rin + nw * si, rout + nw * so, wd + nw
+    A = rnd(torch.randn((rin, Kc), generator=g))
+    lang = torch.randint(0, n_lang, (wd,), generator=g)
+    exp = torch.zeros((rout, half), dtype=torch.float64)
+    for k, (nw, si, so) in enumerate(spec):
+        a = A[cg.row0_in[k]:cg.row0_in[k] + nw * si].double().view(nw, si, Kc)
+        lg = rnd(table)[lang[cg.word0[k]:cg.word0[k] + nw]].double()[:, None, :].expand(nw, si, nb)
+        co = torch.nn.functional.conv1d(torch.cat([a, lg], -1).permute(0, 2, 1), rnd(wf).double(), bf.double(), padding=2)
+        gate = (torch.tanh(co[:, :half]) * torch.sigmoid(co[:, half:])).permute(0, 2, 1)[:, :so, :]
+        exp[cg.row0_out[k]:cg.row0_out[k] + nw * so] = gate.reshape(nw * so, half)
+    ld = packing.p32(half) + 8
+    out = hip.Pair(torch.full((rout + 3, ld), 7.0, dtype=torch.bfloat16, device=dev),
+                   torch.full((rout + 3, ld), 7.0, dtype=torch.bfloat16, device=dev) if split else None)
+    tab = pk["bias_tab" if split else "bias_tab_q"].to(dev)
+    hip.gemm(hip.Pair.split(A, split).to(dev), Kc, rin, pk["Kc"], packing.to_device(pk["W"], dev, with_lo=split), pk["N"],
+             pk["bias"].to(dev), hip.EPI_GATE, out0=out, ldo0=ld, col0=8, taps=5, seq_len=14, n_valid=half,
+             bias_tab=tab, row_group=lang.to(torch.int32).to(dev), groups=cg)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    tol = 1e-4 if split else 1e-2
+    np.testing.assert_allclose(got[:rout, 8:8 + half].numpy(), exp.float().numpy(), rtol=tol, atol=tol)
+    assert (got[rout:] == (14.0 if split else 7.0)).all() and (got[:, :8] == (14.0 if split else 7.0)).all()  # untouched
+
+
 # ------------------------------------------------------------------------------------------
 # cube_mst_decode against the REFERENCE's heads (tests/golden/g4_mst.npz)
 # ------------------------------------------------------------------------------------------

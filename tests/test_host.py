@@ -130,3 +130,34 @@ def test_parser_fails_loudly_without_gpu():
     doc = cases.document(cases.TINY, enc, "single")
     with pytest.raises(hip.CubeHipError):
         p.process(doc, MorphoCollate(enc), batch_size=4)
+
+
+def test_char_layout_covers_what_the_masked_mean_needs():
+    """Parser._char_layout: every word keeps, in layout k, at least min(W, len + 2*(n-k)) positions
+    (so n Conv1d(k=5) layers later positions < len are exact), groups tile the rows without gaps,
+    word_rows point at each word's first row, and > 31 distinct lengths still fit 32 groups."""
+    from cube_amd.networks.parser import Parser
+    from tests import cases
+    cfg, enc, sd = cases.parser_model(cases.TINY)
+    p = Parser(cfg, enc, ext_word_emb=list(cases.TINY["ext"]))
+    n = cfg.char_layers
+    rng = np.random.default_rng(3)
+    for W, lens in ((14, rng.integers(1, 15, size=200)), (40, rng.integers(1, 41, size=500)), (1, np.ones(5, dtype=np.int64)),
+                    (9, np.array([9, 0, 3]))):
+        lens = np.asarray(lens, dtype=np.int64)
+        ch = p._char_layout(lens, W)
+        order = ch["order"]
+        assert sorted(order.tolist()) == list(range(len(lens)))
+        assert len(ch["groups"]) == n and ch["groups"][0].n <= 32
+        for l, cg in enumerate(ch["groups"]):
+            rin = rout = wd = 0
+            for g in range(cg.n):
+                assert (cg.row0_in[g], cg.row0_out[g], cg.word0[g]) == (rin, rout, wd)
+                nw = cg.n_rows[g] // cg.seq_in[g]
+                lg = lens[order[wd:wd + nw]]
+                assert cg.seq_in[g] >= min(W, int(lg.max()) + 2 * (n - l)) and cg.seq_in[g] <= W
+                assert cg.seq_out[g] >= min(W, max(int(lg.max()), 1) + 2 * (n - l - 1))
+                assert cg.seq_out[g] == (ch["groups"][l + 1].seq_in[g] if l + 1 < n else cg.seq_out[g])
+                np.testing.assert_array_equal(ch["word_rows"][l, wd:wd + nw], rout + np.arange(nw) * cg.seq_out[g])
+                rin, rout, wd = rin + cg.n_rows[g], rout + nw * cg.seq_out[g], wd + nw
+            assert (rin, rout, wd) == (ch["rows"][l], ch["rows"][l + 1], len(lens))
