@@ -31,7 +31,7 @@ constexpr int MST_MAX_N = 130;  // L <= 129: S (n*n fp64) + records fit the 160 
 struct MstLds {
   double* S; int ld;
   double* hval; double* dval; double* cs;
-  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn;
+  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn, *dlist;
   uint8_t* rec; int rec_cap;
 };
 
@@ -39,7 +39,7 @@ __host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
 __host__ __device__ inline size_t mst_lds_bytes(int n) {
   const int ld = n | 1;
   const int np = mst_np(n);
-  return (size_t)n * ld * 8 + (size_t)3 * np * 8 + (size_t)12 * np + (size_t)(n * n + 3 * n + 16);
+  return (size_t)n * ld * 8 + (size_t)3 * np * 8 + (size_t)13 * np + (size_t)(n * n + 3 * n + 16);
 }
 
 __device__ inline MstLds mst_carve(unsigned char* smem, int n) {
@@ -51,8 +51,8 @@ __device__ inline MstLds mst_carve(unsigned char* smem, int n) {
   m.hval = reinterpret_cast<double*>(q); q += np * 8;
   m.dval = reinterpret_cast<double*>(q); q += np * 8;
   m.cs = reinterpret_cast<double*>(q); q += np * 8;
-  uint8_t** arr[12] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn};
-  for (int i = 0; i < 12; ++i) { *arr[i] = q; q += np; }
+  uint8_t** arr[13] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn, &m.dlist};
+  for (int i = 0; i < 13; ++i) { *arr[i] = q; q += np; }
   m.rec = q;
   m.rec_cap = n * n + 3 * n + 16;
   return m;
@@ -62,6 +62,26 @@ __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
+}
+
+// First maximum of one row over the current nodes in logical order (NaN counts as maximal, like
+// numpy.argmax).  The two dependent LDS reads per entry (order list, then the score) are issued
+// eight entries at a time: a one-entry-at-a-time loop pays the full LDS latency per entry.
+__device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int cur) {
+  double best = row[m.order[0]];
+  int bi = m.order[0];
+  for (int l0 = 1; l0 < cur; l0 += 8) {
+    int j[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) j[u] = m.order[min(l0 + u, cur - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = row[j[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (l0 + u < cur && (v[u] > best || (v[u] != v[u] && best == best))) { best = v[u]; bi = j[u]; }
+  }
+  return bi;
 }
 
 // Runs the contraction/expansion on the n x n matrix in `m.S` (row = dependent, column = head;
@@ -75,20 +95,21 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
   int cur = n;       // nodes at this level
   int rec_end = 0;   // bytes of records written
   int levels = 0;
+  int ndirty = 0;    // rows whose best head must be re-scanned at the next level
   while (true) {
-    // ---- 1. best head per node, first maximum in logical order
-    for (int li = lane; li < cur; li += 64) {
-      const int k = m.order[li];
-      if (k == 0) { m.tree[0] = 0; continue; }
-      const double* row = S + (size_t)k * ld;
-      double best = row[0];
-      int bi = 0;
-      for (int lj = 1; lj < cur; ++lj) {
-        const int j = m.order[lj];
-        const double v = row[j];
-        if (v > best || (v != v && best == best)) { best = v; bi = j; }
+    // ---- 1. best head per node, first maximum in logical order.  First level: every row, one row
+    // per lane.  Later levels: only the rows whose arg-max can have changed — the contracted node's
+    // row and the rows whose best head was a node of the contracted cycle (`dlist`); for every other
+    // row the old best head survives, keeps its value and still precedes every equal entry (the
+    // survivors keep their relative order, the contracted node goes last), so a full re-scan would
+    // return it again.  One row per lane, eight entries in flight per lane.
+    {
+      const int nscan = (levels == 0) ? cur : ndirty;
+      for (int li = lane; li < nscan; li += 64) {
+        const int k = (levels == 0) ? m.order[li] : m.dlist[li];
+        if (k == 0) { m.tree[0] = 0; continue; }
+        m.tree[k] = (uint8_t)scan_row(m, S + (size_t)k * ld, cur);
       }
-      m.tree[k] = (uint8_t)bi;
     }
     __syncthreads();
     // ---- 2. cycles by pointer doubling: p = f^(2^r), mn = smallest logical position on the walk
@@ -198,6 +219,23 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       m.order[a] = (uint8_t)j;
       m.pos[j] = (uint8_t)a;
     }
+    // rows to re-scan: survivors whose best head sat in the cycle, and the contracted node itself
+    ndirty = 0;
+    for (int base = 0; base < nn; base += 64) {
+      const int a = base + lane;
+      int j = 0;
+      bool dty = false;
+      if (a < nn) {
+        j = norder[a];
+        dty = (j != 0) && m.incyc[m.tree[j]];
+      }
+      const unsigned long long bd = __ballot(dty);
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      if (dty) m.dlist[ndirty + __popcll(bd & below)] = (uint8_t)j;
+      ndirty += __popcll(bd);
+    }
+    if (lane == 0) m.dlist[ndirty] = (uint8_t)slot_m;
+    ++ndirty;
     for (int i = 1 + lane; i < c; i += 64) m.alive[m.clist[i]] = 0;
     if (lane == 0) {
       S[(size_t)slot_m * ld + slot_m] = 0.0;
@@ -260,16 +298,32 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
 
 // S[k][j] for k >= 1 from the probability tensor (utils.py:569-574): crop to n columns, zero diagonal
 __device__ inline void build_scores(const MstLds& m, const float* p, int n, int T, int lane, int root) {
-  for (int k = 1; k < n; ++k) {
-    const float* pr = p + (size_t)(k - 1) * T;
-    double* row = m.S + (size_t)k * m.ld;
-    for (int j = lane; j < n; j += 64) {
-      double v = (j == k) ? 0.0 : (double)pr[j];
-      if (root > 0) {  // set_root (utils.py:537-543)
-        if (j == 0) v = (k == root) ? 1.0 : 0.0;
-        else if (k == root) v = 0.0;
+  // flattened over (k, j) with 8 independent loads in flight per lane (a row-by-row loop pays one
+  // global-load latency per row: ~130 us of a 129-node task)
+  const int total = (n - 1) * n;
+  for (int e0 = lane; e0 < total; e0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 64 * u;
+      v[u] = 0.f;
+      if (e < total) {
+        const int k = e / n + 1, j = e - (k - 1) * n;
+        v[u] = p[(size_t)(k - 1) * T + j];
       }
-      row[j] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 64 * u;
+      if (e < total) {
+        const int k = e / n + 1, j = e - (k - 1) * n;
+        double d = (j == k) ? 0.0 : (double)v[u];
+        if (root > 0) {  // set_root (utils.py:537-543)
+          if (j == 0) d = (k == root) ? 1.0 : 0.0;
+          else if (k == root) d = 0.0;
+        }
+        m.S[(size_t)k * m.ld + j] = d;
+      }
     }
   }
   __syncthreads();
