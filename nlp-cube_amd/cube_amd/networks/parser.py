@@ -193,11 +193,17 @@ class _HipNet:
                  "lens", "word_rows")
         bt = {n: ints[o:o + s] for n, o, s in zip(names, offs[:-1], sizes)}
         embs = []
+        dst = None if N == B * L else torch.from_numpy(sb * L + si).to(dev, non_blocking=True)
         for k, e in enumerate(X["x_word_embeddings"]):
+            # fp32 upload; padding to [B*L, Epad] and the hi/lo split run on the device
             ek = self._pk["ext"][k]
-            pad = torch.zeros((B * L, ek["Epad"]), dtype=torch.float32)
-            pad[torch.from_numpy(sb * L + si), :ek["E"]] = e.cpu().to(torch.float32)
-            embs.append(hip.Pair.split(pad, with_lo=self._split).to(dev))
+            e = e.to(dev, non_blocking=True).to(torch.float32)
+            pad = torch.zeros((B * L, ek["Epad"]), dtype=torch.float32, device=dev)
+            if dst is None:
+                pad[:, :ek["E"]] = e
+            else:
+                pad[dst, :ek["E"]] = e
+            embs.append(hip.Pair.split(pad, with_lo=self._split))
         bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs, conv_groups=ch["groups"], char_rows=ch["rows"])
         if "y_upos" in X:
             bt["y_upos"] = X["y_upos"].to(dev).to(torch.int32).contiguous()
@@ -594,14 +600,15 @@ class Parser(_HipNet):
             raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
                                  % (start + np.where(status != 0)[0]).tolist())
         enc = self._encodings
+        tabs = getattr(self, "_str_tabs", None)
+        if tabs is None:  # id -> string tables as object arrays: one fancy-index per batch instead of a list lookup per word
+            tabs = self._str_tabs = tuple(np.asarray(t, dtype=object) for t in
+                                          (enc.labels, enc.upos_list, enc.xpos_list, enc.attrs_list))
         heads = res[0].astype(np.int64)
+        lab, up, xp, at = tabs[0][res[1]], tabs[1][res[2]], tabs[2][res[3]], tabs[3][res[4]]
         for b, s in enumerate(batch):
-            for i, w in enumerate(s.words):
-                w.head = heads[b, i]
-                w.label = enc.labels[res[1, b, i]]
-                w.upos = enc.upos_list[res[2, b, i]]
-                w.xpos = enc.xpos_list[res[3, b, i]]
-                w.attrs = enc.attrs_list[res[4, b, i]]
+            for w, h, l, u, x, a in zip(s.words, heads[b], lab[b], up[b], xp[b], at[b]):
+                w.head, w.label, w.upos, w.xpos, w.attrs = h, l, u, x, a
 
     def process(self, doc, collate, batch_size=4, num_workers=4):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
@@ -613,7 +620,7 @@ class Parser(_HipNet):
         pending = None
         for start in range(0, len(sents), batch_size):
             batch = sents[start:start + batch_size]
-            X = collate.collate_fn(batch)
+            X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
             X.pop("y_upos", None)
             ticket = self.submit(self._prepare(X))
             if pending is not None:

@@ -69,7 +69,7 @@ class Tagger(_HipNet):
         sents = doc.sentences
         for start in range(0, len(sents), batch_size):
             batch = sents[start:start + batch_size]
-            X = collate.collate_fn(batch)
+            X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
             X.pop("y_upos", None)
             res = self.tag_batch(X)["packed"].cpu().numpy()
             for b, s in enumerate(batch):

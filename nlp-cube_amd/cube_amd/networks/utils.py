@@ -45,35 +45,59 @@ class MorphoCollate:
             self._case_cache[ch] = hit
         return hit
 
-    def collate_fn(self, batch):
+    def _char_tables(self, cps):
+        """code point -> (char id, case id) lookup arrays, grown on demand (the per-character rule of
+        `_char_codes` is evaluated once per distinct character, then applied by fancy indexing)."""
+        top = int(cps.max()) + 1 if len(cps) else 1
+        tab = getattr(self, "_cp_tab", None)
+        if tab is None or tab.shape[1] < top:
+            new = np.full((2, max(top, 256)), -1, dtype=np.int64)
+            if tab is not None:
+                new[:, :tab.shape[1]] = tab
+            self._cp_tab = tab = new
+        missing = np.unique(cps[tab[0, cps] < 0])
+        for cp in missing.tolist():
+            tab[:, cp] = self._char_codes(chr(cp))
+        return tab
+
+    def collate_fn(self, batch, targets=True):
+        """`targets=False` (used by `process`, which drops them anyway) skips the y_* tensors."""
         enc = self._encodings
         sent_len = np.fromiter((len(s.words) for s in batch), dtype=np.int64, count=len(batch))
         words = [w for s in batch for w in s.words]
-        word_len = np.fromiter((len(w.word) for w in words), dtype=np.int64, count=len(words))
+        texts = [w.word for w in words]
+        word_len = np.fromiter(map(len, texts), dtype=np.int64, count=len(words))
         B, L, N, W = len(batch), int(sent_len.max()), len(words), int(word_len.max())
         K = len(words[0].emb)
         w2i, unk = enc.word2int, enc.word2int["<UNK>"]
-        # flat character stream -> (word, position) scatter
-        codes = [self._char_codes(ch) for w in words for ch in w.word]
-        flat = np.asarray(codes, dtype=np.int64).reshape(-1, 2)
+        # flat character stream (UTF-32 code points of all words) -> (word, position) scatter
+        cps = np.frombuffer("".join(texts).encode("utf-32-le", "surrogatepass"), dtype=np.uint32).astype(np.int64)
+        tab = self._char_tables(cps)
         wi = np.repeat(np.arange(N), word_len)
         starts = np.cumsum(word_len) - word_len
         pi = np.arange(len(wi)) - np.repeat(starts, word_len)
         x_word = np.zeros((N, W), dtype=np.int64)
         x_word_case = np.zeros((N, W), dtype=np.int64)
         x_word_masks = np.zeros((N, W), dtype=np.float64)
-        x_word[wi, pi] = flat[:, 0]
-        x_word_case[wi, pi] = flat[:, 1]
+        x_word[wi, pi] = tab[0, cps]
+        x_word_case[wi, pi] = tab[1, cps]
         x_word_masks[wi, pi] = 1
         sb = np.repeat(np.arange(B), sent_len)
         si = np.arange(N) - np.repeat(np.cumsum(sent_len) - sent_len, sent_len)
         x_sent = np.zeros((B, L), dtype=np.int64)
         x_sent_masks = np.zeros((B, L), dtype=np.float64)
-        x_sent[sb, si] = np.fromiter((w2i.get(w.word.lower(), unk) for w in words), dtype=np.int64, count=N)
+        x_sent[sb, si] = np.fromiter((w2i.get(t.lower(), unk) for t in texts), dtype=np.int64, count=N)
         x_sent_masks[sb, si] = 1
         x_lang_sent = np.fromiter((s.lang_id + 1 for s in batch), dtype=np.int64, count=B)
         x_lang_word = np.repeat(x_lang_sent, sent_len)
-        embs = [torch.from_numpy(np.asarray([w.emb[k] for w in words])) for k in range(K)]
+        embs = []
+        for k in range(K):
+            rows = [w.emb[k] for w in words]
+            try:
+                e = np.concatenate(rows).reshape(N, -1)
+            except ValueError:  # not arrays of one length: let NumPy sort it out the slow way
+                e = np.asarray(rows)
+            embs.append(torch.from_numpy(np.ascontiguousarray(e)))
         out = {
             "x_sent": torch.from_numpy(x_sent), "x_lang_sent": torch.from_numpy(x_lang_sent),
             "x_word": torch.from_numpy(x_word), "x_word_case": torch.from_numpy(x_word_case),
@@ -81,6 +105,8 @@ class MorphoCollate:
             "x_word_len": torch.from_numpy(word_len), "x_sent_masks": torch.from_numpy(x_sent_masks),
             "x_word_masks": torch.from_numpy(x_word_masks), "x_word_embeddings": embs,
         }
+        if not targets:
+            return out
 
         def targets(attr, table):
             y = np.zeros((B, L), dtype=np.int64)
