@@ -65,6 +65,11 @@ def run_steps(p, batches, n):
     `collect`: the latency-bound second phase of a step overlaps the first phase of the next)."""
     pending = None
     out = None
+    if os.environ.get("CUBE_BENCH_SERIAL") == "1":  # profiling aid: one stream, kernels never overlap
+        for i in range(n):
+            r = p.decode_batch_prepared(batches[i % len(batches)])
+            out = r["packed"].cpu()
+        return out
     for i in range(n):
         t = p.submit(batches[i % len(batches)])
         if pending is not None:
@@ -111,7 +116,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = world > 1
+    dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if dist:

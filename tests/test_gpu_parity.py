@@ -433,3 +433,65 @@ def test_tagger_process_needs_a_flag(dev):
     t, cfg, enc, sd = _tagger(dev, cases.TINY_TAGGER)
     with pytest.raises(Exception):
         t.process(cases.document(cases.TINY_TAGGER, enc, "single"), MorphoCollate(enc), upos=False, xpos=False, attrs=False)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs[1] at full size (B=256 x L=32, full width): size-independent properties
+# ------------------------------------------------------------------------------------------
+def _is_single_rooted_tree(heads):
+    n = len(heads)
+    if (heads == 0).sum() != 1 or heads.min() < 0 or heads.max() > n:
+        return False
+    for k in range(1, n + 1):  # every node reaches the root without revisiting a node
+        seen, cur = 0, k
+        while cur != 0:
+            cur = int(heads[cur - 1])
+            seen += 1
+            if seen > n:
+                return False
+    return True
+
+
+def test_full_size_batch_properties(dev):
+    """The bench workload itself (256 sentences x 32 tokens, default config): (1) every decoded
+    sentence is a single-rooted tree; (2) a sentence's scores do not depend on how many other
+    sentences share the batch — bitwise, when padded word length and sentence length are the
+    same (rows are independent and their K order is fixed); (3) a sub-batch agrees with the fp32
+    oracle to the north-star tolerance."""
+    from oracle import parser_oracle
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    p, cfg, enc, sd = _model(dev, cases.FULL, "bf16x3")
+    doc = synth.make_document(enc, [32] * 256, seed=1001, ext_word_emb=(300,))
+    col = MorphoCollate(enc)
+    X = col.collate_fn(doc.sentences, targets=False)
+    r = p.decode_batch(X)
+    arc = r["arc_logits"].cpu().numpy().copy()
+    heads = r["heads"].cpu().numpy().copy()
+    lab = r["label_logits"].cpu().numpy().copy()
+    upos = r["upos_logits"].cpu().numpy().copy()
+    assert (r["status"].cpu().numpy() == 0).all()
+    for b in range(256):
+        assert _is_single_rooted_tree(heads[b]), b
+    # sub-batch with the same padded word length W
+    W = int(X["x_word_len"].max())
+    wl = X["x_word_len"].numpy().reshape(256, 32)
+    keep = list(range(16))
+    if wl[:16].max() < W:
+        keep.append(int(np.argmax(wl.max(axis=1) == W)))
+    sub = [doc.sentences[i] for i in keep]
+    Xs = col.collate_fn(sub, targets=False)
+    assert int(Xs["x_word_len"].max()) == W
+    rs = p.decode_batch(Xs)
+    np.testing.assert_array_equal(rs["arc_logits"].cpu().numpy(), arc[keep])
+    np.testing.assert_array_equal(rs["label_logits"].cpu().numpy(), lab[keep])
+    np.testing.assert_array_equal(rs["upos_logits"].cpu().numpy(), upos[keep])
+    np.testing.assert_array_equal(rs["heads"].cpu().numpy(), heads[keep])
+    ora = parser_oracle.OracleParser(cfg, enc, sd, [300], quant="fp32")
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        e = ora.decode_batch(parser_oracle.collate(sub, enc))
+    assert _rel(arc[keep], e["arc_logits"]) < REL_TOL
+    assert _rel(upos[keep], e["upos_logits"]) < REL_TOL
+    agree = np.mean([np.array_equal(heads[k][:32], h) for k, h in zip(keep, e["heads"])])
+    assert agree == 1.0, agree
