@@ -26,7 +26,9 @@
 
 namespace {
 
-constexpr int MST_MAX_N = 130;  // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
+constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
+constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences (node ids are bytes): S lives in the workspace (HBM/L2), slow but exact
+constexpr int MST_GLOBAL_ROOT_BLOCKS = 256;  // workgroups (= private score matrices) of the root kernel in that mode
 
 struct MstLds {
   double* S; int ld;
@@ -36,18 +38,18 @@ struct MstLds {
 };
 
 __host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
-__host__ __device__ inline size_t mst_lds_bytes(int n) {
+__host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false) {
   const int ld = n | 1;
   const int np = mst_np(n);
-  return (size_t)n * ld * 8 + (size_t)3 * np * 8 + (size_t)13 * np + (size_t)(n * n + 3 * n + 16);
+  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)3 * np * 8 + (size_t)13 * np + (size_t)(n * n + 3 * n + 16);
 }
 
-__device__ inline MstLds mst_carve(unsigned char* smem, int n) {
+__device__ inline MstLds mst_carve(unsigned char* smem, int n, double* global_s = nullptr) {
   MstLds m;
   const int np = mst_np(n);
   m.ld = n | 1;
-  m.S = reinterpret_cast<double*>(smem);
-  unsigned char* q = smem + (size_t)n * m.ld * 8;
+  m.S = global_s ? global_s : reinterpret_cast<double*>(smem);
+  unsigned char* q = smem + (global_s ? 0 : (size_t)n * m.ld * 8);
   m.hval = reinterpret_cast<double*>(q); q += np * 8;
   m.dval = reinterpret_cast<double*>(q); q += np * 8;
   m.cs = reinterpret_cast<double*>(q); q += np * 8;
@@ -337,12 +339,17 @@ struct MstWs {
   int32_t* task_root;   // [B*L]
   double* task_score;   // [B*L]
   uint8_t* task_tree;   // [B*L][L+1]
+  double* s_first;      // long-sentence mode only: [B][n_max * ld] score matrices of the first pass
+  double* s_root;       // and [MST_GLOBAL_ROOT_BLOCKS][n_max * ld] of the root pass
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ inline size_t mst_s_elems(int L) { return (size_t)(L + 1) * ((L + 1) | 1); }
 __host__ inline size_t mst_ws_bytes(int B, int L) {
   const size_t nt = (size_t)B * L;
-  return 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1));
+  size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1));
+  if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * ((size_t)B + MST_GLOBAL_ROOT_BLOCKS);
+  return b;
 }
 __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
   MstWs w;
@@ -354,10 +361,13 @@ __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
   w.task_sent = (int32_t*)q; q += align16(4 * nt);
   w.task_root = (int32_t*)q; q += align16(4 * nt);
   w.task_score = (double*)q; q += align16(8 * nt);
-  w.task_tree = (uint8_t*)q;
+  w.task_tree = (uint8_t*)q; q += align16(nt * (L + 1));
+  w.s_first = (double*)q;
+  w.s_root = w.s_first + (L + 1 > MST_MAX_N ? mst_s_elems(L) * B : 0);
   return w;
 }
 
+template <bool GS>  // GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words)
 __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
                                                        int B, int L, int32_t* heads, int32_t* status, MstWs ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
   if (lane == 0) { ws.sent_cnt[b] = 0; ws.sent_base[b] = 0; status[b] = 0; }
   if (len == 0) return;
   const float* p = probs + (size_t)b * L * T;
-  MstLds m = mst_carve(smem, n);
+  MstLds m = mst_carve(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr);
   build_scores(m, p, n, T, lane, 0);
   if (!cle_run(m, n, lane)) { if (lane == 0) status[b] = 2; return; }
   __syncthreads();
@@ -437,6 +447,7 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
   }
 }
 
+template <bool GS>
 __global__ __launch_bounds__(64) void mst_root_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
                                                       int B, int L, MstWs ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(64) void mst_root_kernel(const float* __restrict__ 
     const int root = ws.task_root[t];
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
-    MstLds m = mst_carve(smem, n);
+    MstLds m = mst_carve(smem, n, GS ? ws.s_root + (size_t)blockIdx.x * T * (T | 1) : nullptr);
     build_scores(m, p, n, T, lane, root);
     uint8_t* tt = ws.task_tree + (size_t)t * T;
     if (!cle_run(m, n, lane)) {
@@ -513,31 +524,36 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
                                void* workspace, size_t workspace_bytes, void* stream) {
   if (B <= 0 || L <= 0) return CUBE_OK;
   if (!probs || !lens || !heads || !status || !workspace) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: null pointer");
-  if (L + 1 > MST_MAX_N) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N - 1);
+  if (L + 1 > MST_MAX_N_GLOBAL) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
   if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
   if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = mst_lds_bytes(L + 1);
-  static size_t lds_set_first = 0, lds_set_root = 0;
-  if (lds > 65536) {
-    if (lds > lds_set_first) {
-      if (hipFuncSetAttribute((const void*)mst_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const bool gs = L + 1 > MST_MAX_N;
+  const size_t lds = mst_lds_bytes(L + 1, gs);
+  static size_t lds_set[4] = {0, 0, 0, 0};
+  const void* fns[4] = {(const void*)mst_first_kernel<false>, (const void*)mst_root_kernel<false>,
+                        (const void*)mst_first_kernel<true>, (const void*)mst_root_kernel<true>};
+  for (int k = gs ? 2 : 0; k < (gs ? 4 : 2); ++k) {
+    if (lds > 65536 && lds > lds_set[k]) {
+      if (hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
-      lds_set_first = lds;
-    }
-    if (lds > lds_set_root) {
-      if (hipFuncSetAttribute((const void*)mst_root_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
-      lds_set_root = lds;
+      lds_set[k] = lds;
     }
   }
   MstWs ws = mst_ws_carve(workspace, B, L);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
-  hipLaunchKernelGGL(mst_first_kernel, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
-  CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
   int nblk = B * L;
   if (nblk > 4096) nblk = 4096;
-  hipLaunchKernelGGL(mst_root_kernel, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+  if (gs) {
+    if (nblk > MST_GLOBAL_ROOT_BLOCKS) nblk = MST_GLOBAL_ROOT_BLOCKS;
+    hipLaunchKernelGGL(mst_first_kernel<true>, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
+    CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
+    hipLaunchKernelGGL(mst_root_kernel<true>, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+  } else {
+    hipLaunchKernelGGL(mst_first_kernel<false>, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
+    CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
+    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+  }
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
   hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
   CUBE_CHECK_LAUNCH("cube_mst_decode(select)");

@@ -195,11 +195,14 @@ class TraceLib:
     def cube_mst_workspace_bytes(B, L):
         a16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
         nt = B * L
-        return 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * (L + 1))
+        b = 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * (L + 1))
+        if L + 1 > 130:  # long-sentence mode: score matrices in the workspace
+            b += 8 * (L + 1) * ((L + 1) | 1) * (B + 256)
+        return b
 
     def cube_mst_decode(self, probs, lens, B, L, heads, status, ws, ws_bytes, stream):
         self.calls.append(("mst", B, L))
-        assert L + 1 <= 130 and ws_bytes >= self.cube_mst_workspace_bytes(B, L)
+        assert L + 1 <= 255 and ws_bytes >= self.cube_mst_workspace_bytes(B, L)
         self._need("mst probs", probs, 4 * B * L * (L + 1), 4)
         self._need("mst lens", lens, 4 * B, 4)
         self._need("mst heads", heads, 4 * B * L, 4)

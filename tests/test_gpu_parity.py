@@ -215,6 +215,26 @@ def test_mst_matches_reference_heads(dev, golden_dir):
             np.testing.assert_array_equal(h, exp[b, :len(h)], err_msg="%s[%d]" % (key, b))
 
 
+def test_mst_long_sentences_match_oracle(dev):
+    """Sentences of 130..254 words (score matrix in the workspace instead of LDS) against the NumPy
+    restatement of the reference decoder (itself pinned by G4); 255+ words are refused."""
+    from oracle import cle_oracle
+    from cube_amd.networks.utils import ChuLiuEdmondsDecoder
+    dec = ChuLiuEdmondsDecoder(dev)
+    rng = np.random.default_rng(17)
+    for L, B, sigma in ((130, 3, 4.0), (200, 2, 6.0), (254, 2, 8.0)):
+        logits = rng.standard_normal((B, L, L + 1)) * sigma
+        e = np.exp(logits - logits.max(-1, keepdims=True))
+        probs = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+        lens = np.array([L] + [int(rng.integers(100, L)) for _ in range(B - 1)], dtype=np.int64)
+        got = dec.decode(probs, lens)
+        exp = cle_oracle.decode(probs, lens)
+        for b in range(B):
+            np.testing.assert_array_equal(got[b], exp[b], err_msg="L=%d b=%d" % (L, b))
+    with pytest.raises(Exception):
+        dec.decode(np.full((1, 255, 256), 1.0 / 256, dtype=np.float32), np.array([255]))
+
+
 # ------------------------------------------------------------------------------------------
 # whole path: bf16x3 against the REFERENCE's outputs (golden) and the fp32 oracle;
 #             bf16 (single pass) against the bf16-contract oracle
