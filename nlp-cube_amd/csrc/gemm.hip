@@ -27,16 +27,28 @@ constexpr int ROWB = 64;  // bytes per LDS row (32 bf16); 16-byte chunks XOR-swi
 // Tile configurations.  Big: 256x256, 8 waves (2x4), 128x64 per wave — half the LDS fill per MFMA
 // of the small one (the ds_write path, ~79 B/clk/CU, is what bounds a 128x128 tile).  Small:
 // 128x128, 4 waves (2x2), 64x64 per wave, 2 blocks/CU — for the GEMMs with few rows.
-struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4; };
-struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
+// SR = activation slab rows in LDS (a multiple of the 16 rows one LDS-DMA piece fills).  A tile is
+// BM OUTPUT rows; the slab holds the input rows they read (+ halo).  For plain sequences that is
+// BM + 4 rows; with ragged groups (seq_out < seq_in: the last positions of every sequence are read
+// as neighbours but produce no output) the input span of a tile is up to seq_in/seq_out longer, so
+// the slab is made as large as the 160 KiB of LDS allow and a tile takes fewer rows if it must.
+struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, SR = 352; };
+struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, SR = 176; };
 
 constexpr int MAX_TAPS = 5;
-// slab rows allocated in LDS: tile rows + halo, rounded to the 16 rows one LDS-DMA piece fills
-template <class C> constexpr int slab_rows() { return (C::BM + MAX_TAPS - 1 + 15) / 16 * 16; }
+template <class C> constexpr int slab_rows() { return C::SR; }
 // LDS: [A slab x2 buffers][B tile x2 buffers][one zero row][per tile row: bias-table offset, output
-// row, tap mask]; every operand buffer holds NP planes
+// row, tap mask, slab row]; every operand buffer holds NP planes
 template <class C, bool SPLIT> constexpr int lds_bytes() {
-  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + 3 * C::BM * 4;
+  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + 4 * C::BM * 4;
+}
+// output rows one tile of a sequence group takes: all BM unless the input rows they read would
+// not fit the slab.  r rows touch at most (r-2)/seq_out + 2 sequences of seq_in rows each.
+__host__ __device__ inline int tile_rows(int BM, int SR, int seq_in, int seq_out) {
+  if (seq_in == seq_out) return BM;
+  const int q = (SR - (MAX_TAPS - 1)) / seq_in;  // whole sequences the slab can hold
+  const int r = (q - 1) * seq_out + 1;
+  return r < BM ? r : BM;
 }
 
 struct GemmParams {
@@ -79,7 +91,7 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 }
 
 // K loop order: channel chunk kc (32 channels) outer, tap inner; k-step s = kc*taps + tap reads
-// W[n][s*32 .. s*32+32).  For each kc the block stages the A rows [m0 - taps/2, m0 + BM + taps/2)
+// W[n][s*32 .. s*32+32).  For each kc the block stages the A rows its output rows read (+ taps/2 halo)
 // x 32 channels ONCE (the "slab") and the taps read it at shifted rows: the activations cross
 // HBM/L2 -> LDS once per output tile instead of once per tap.  Rows that a tap would take from a
 // neighbouring sequence (Conv1d zero padding) are redirected, per lane, to a zero row in LDS.
@@ -110,19 +122,25 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int mt = (slot / p.n_tiles) * 8 + xcd;
   if (mt >= p.m_tiles) return;  // whole block: before any barrier
-  // the row tile's sequence group (one implicit group = the whole matrix when cg.n == 0)
-  int row_lo = 0, row_hi = p.M, seq = p.seq_len, seq_out = p.seq_len, row0_out = 0, word0 = 0, m0 = mt * BM;
+  // the row tile's sequence group (one implicit group = the whole matrix when cg.n == 0): the tile
+  // takes output rows [ro0, ro0 + bm) of the group; in0 = the input row its first output row reads
+  int row_lo = 0, seq = p.seq_len, seq_out = p.seq_len, row0_out = 0, word0 = 0;
+  int n_out = p.M, ro0 = mt * BM, bm = BM;
   if (cg.n > 0) {
     int g = 0, t0 = 0;
-    for (; g < cg.n - 1; ++g) {
-      const int nt = (cg.n_rows[g] + BM - 1) / BM;
-      if (mt < t0 + nt) break;
+    for (;; ++g) {
+      bm = tile_rows(BM, SR, cg.seq_in[g], cg.seq_out[g]);
+      n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+      const int nt = (n_out + bm - 1) / bm;
+      if (mt < t0 + nt || g == cg.n - 1) break;
       t0 += nt;
     }
-    row_lo = cg.row0_in[g]; row_hi = row_lo + cg.n_rows[g]; seq = cg.seq_in[g]; seq_out = cg.seq_out[g];
+    row_lo = cg.row0_in[g]; seq = cg.seq_in[g]; seq_out = cg.seq_out[g];
     row0_out = cg.row0_out[g]; word0 = cg.word0[g];
-    m0 = row_lo + (mt - t0) * BM;
+    ro0 = (mt - t0) * bm;
   }
+  const int m0 = ro0;  // first output row of the tile (plain sequences: output row = input row)
+  const int in0 = row_lo + (ro0 / seq_out) * seq + ro0 % seq_out;
   const int n0 = (slot % p.n_tiles) * BN;
   const int taps = p.taps;
   const int half_taps = taps >> 1;
@@ -132,26 +150,28 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 
   if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
   // per tile row, computed once (one division per row): which taps fall inside the row's sequence,
-  // where its output goes (-1: nowhere) and the offset of its bias vector in bias_tab.  Read after
-  // the first barrier below.
-  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB, OROW_OFF = ROWOFF_OFF + BM * 4, MASK_OFF = OROW_OFF + BM * 4;
+  // where its output goes (-1: nowhere), which slab row it reads and the offset of its bias vector
+  // in bias_tab.  Read after the first barrier below.
+  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB, OROW_OFF = ROWOFF_OFF + BM * 4, MASK_OFF = OROW_OFF + BM * 4,
+                AROW_OFF = MASK_OFF + BM * 4;
   if (tid < BM) {
-    const int row = m0 + tid;
+    const int ro = ro0 + tid;
     unsigned off = 0, m = 0;
-    int orow = -1;
-    if (row < row_hi) {
-      const int rel = row - row_lo;
-      const int j = rel / seq, pos = rel - j * seq;
+    int orow = -1, arow = 0;
+    if (tid < bm && ro < n_out) {
+      const int j = ro / seq_out, pos = ro - j * seq_out;
       for (int t = 0; t < taps; ++t) {
         const int pp = pos + t - half_taps;
         if (pp >= 0 && pp < seq) m |= 1u << t;
       }
-      if (pos < seq_out) orow = row0_out + j * seq_out + pos;
-      if (p.bias_tab) off = ((unsigned)p.row_group[cg.n > 0 ? word0 + j : row] * 32u + m) * (unsigned)p.N;
+      orow = row0_out + ro;
+      arow = row_lo + j * seq + pos - in0;
+      if (p.bias_tab) off = ((unsigned)p.row_group[cg.n > 0 ? word0 + j : ro] * 32u + m) * (unsigned)p.N;
     }
     reinterpret_cast<uint32_t*>(smem + ROWOFF_OFF)[tid] = off;
     reinterpret_cast<int32_t*>(smem + OROW_OFF)[tid] = orow;
     reinterpret_cast<uint32_t*>(smem + MASK_OFF)[tid] = m;
+    reinterpret_cast<int32_t*>(smem + AROW_OFF)[tid] = arow;
   }
 
   // ---- DMA source offsets (elements) of this lane for the pieces its wave issues
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int row = 16 * (wid + NW * i) + prow;           // slab row
-      long g = (long)m0 - half_taps + row;                  // global activation row, clamped: rows
+      long g = (long)in0 - half_taps + row;                 // global activation row, clamped: rows
       g = g < 0 ? 0 : (g >= p.M ? p.M - 1 : g);             // outside [0, M) are never read unmasked
       a_src[i] = (size_t)g * p.lda + ((ppos ^ ((row >> 2) & 3)) << 3);
     }
@@ -176,8 +196,6 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int l31 = lane & 31, lh = lane >> 5;
   int a_row[TM];
   unsigned vmask[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) a_row[i] = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
   int b_rd[TN][2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -214,7 +232,11 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   ISSUE_B(0, 0)
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < TM; ++i) vmask[i] = reinterpret_cast<const uint32_t*>(smem + MASK_OFF)[a_row[i]];
+  for (int i = 0; i < TM; ++i) {
+    const int lr = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
+    vmask[i] = reinterpret_cast<const uint32_t*>(smem + MASK_OFF)[lr];
+    a_row[i] = reinterpret_cast<const int32_t*>(smem + AROW_OFF)[lr];  // slab row of tap 0 is a_row + 0: the slab starts half_taps rows early
+  }
 
   int kc = 0, tap = 0;
   for (int s = 0; s < nk; ++s) {
@@ -430,7 +452,12 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   p.m_tiles = (p.M + C::BM - 1) / C::BM;
   if (cg.n > 0) {
     p.m_tiles = 0;
-    for (int g = 0; g < cg.n; ++g) p.m_tiles += (cg.n_rows[g] + C::BM - 1) / C::BM;
+    for (int g = 0; g < cg.n; ++g) {
+      const int bm = tile_rows(C::BM, C::SR, cg.seq_in[g], cg.seq_out[g]);
+      if (bm < 1) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: sequences of %d rows do not fit the activation slab", cg.seq_in[g]);
+      const int n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+      p.m_tiles += (n_out + bm - 1) / bm;
+    }
   }
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
   hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
