@@ -161,3 +161,57 @@ def test_char_layout_covers_what_the_masked_mean_needs():
                 np.testing.assert_array_equal(ch["word_rows"][l, wd:wd + nw], rout + np.arange(nw) * cg.seq_out[g])
                 rin, rout, wd = rin + cg.n_rows[g], rout + nw * cg.seq_out[g], wd + nw
             assert (rin, rout, wd) == (ch["rows"][l], ch["rows"][l + 1], len(lens))
+
+
+def test_abi_rejects_bad_arguments():
+    """Every entry point validates its arguments before touching the device and reports through
+    the return code + cube_last_error() (no GPU needed: nothing is launched)."""
+    lib = hip.load()
+    P = 0x10000  # a non-null, 16-byte aligned stand-in pointer: never dereferenced on these paths
+
+    def err(code):
+        assert code < 0
+        msg = lib.cube_last_error().decode()
+        assert msg.startswith("cube_"), msg
+        return msg
+
+    def gemm(**kw):
+        a = hip.GemmArgs()
+        a.A, a.W, a.lda, a.M, a.seq_len, a.taps, a.Kc, a.N = P, P, 64, 128, 128, 1, 64, 128
+        a.epilogue, a.out0, a.ldo0, a.n_valid = hip.EPI_F32, P, 128, 128
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return lib.cube_gemm_bf16(ctypes.byref(a), None)
+
+    assert "Kc" in err(gemm(Kc=33))
+    assert "N=" in err(gemm(N=100))
+    assert "taps" in err(gemm(taps=4))
+    assert "A_lo and W_lo" in err(gemm(A_lo=P))
+    assert "lda" in err(gemm(lda=60))
+    assert "aligned" in err(gemm(A=P + 2))
+    assert "seq_len" in err(gemm(taps=5, seq_len=100))
+    assert "out0" in err(gemm(ldo0=64))
+    assert "unknown epilogue" in err(gemm(epilogue=9))
+    assert "bias" in err(gemm(epilogue=hip.EPI_GATE, n_valid=64))
+    assert "rowmap" in err(gemm(epilogue=hip.EPI_GATE, n_valid=64, bias=P, rowmap=P))
+    assert "bias_tab" in err(gemm(bias_tab=P))
+    cg = hip.ConvGroups()
+    cg.n = 40
+    assert "sequence groups" in err(gemm(epilogue=hip.EPI_GATE, n_valid=64, bias=P, groups=ctypes.pointer(cg)))
+    cg.n = 1
+    cg.n_rows[0], cg.seq_in[0], cg.seq_out[0] = 100, 7, 5  # 100 rows are not whole sequences of 7
+    assert "sequence group" in err(gemm(epilogue=hip.EPI_GATE, n_valid=64, bias=P, taps=5, groups=ctypes.pointer(cg)))
+    assert gemm(M=0) == 0  # nothing to do is not an error
+
+    assert "columns" in err(lib.cube_gather_rows(P, None, 64, 60, 8, P, None, 8, None, None, 4, None))
+    layers = (ctypes.c_void_p * 9)(*([P] * 9))
+    assert "n_layers" in err(lib.cube_masked_mean(layers, None, None, 9, 64, P, 4, 3, 64, P, None, 64, None, None))
+    assert "bad args" in err(lib.cube_argmax_rows(P, 16, 10, 8, 4, P, None))
+    assert "rnn_size" in err(lib.cube_bilstm_recurrent(P, P, None, 4, 5, 300, P, None, 640, 0, None))
+    assert "whh_lo" in err(lib.cube_bilstm_recurrent(P, P, P, 4, 5, 200, P, None, 448, 0, None))
+    assert "D/columns" in err(lib.cube_biaffine_arc(P, None, 128, P, None, 256, 128, 100, 2, 9, P, P, None))
+    assert "longer than" in err(lib.cube_mst_decode(P, P, 1, 300, P, P, P, 1 << 30, None))
+    assert "workspace too small" in err(lib.cube_mst_decode(P, P, 4, 16, P, P, P, 16, None))
+    assert lib.cube_mst_workspace_bytes(4, 200) > lib.cube_mst_workspace_bytes(4, 100) > 0
+    assert "D/columns" in err(lib.cube_label_score(P, None, 448, 224, 288, P, None, P, 10, P, P, 2, 3, P, P, None))
+    assert "bad args" in err(lib.cube_ext_finish(P, 8, 2, 3, 2, 2, 1, P, None, 64, 0, None, None, 0, 0, None))  # root = 2
