@@ -31,7 +31,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CONFIGS = {1: dict(B=256, L=32, name="en parser+tagger B=256 x L=32 (BASELINE configs[1])"),
-           2: dict(B=64, L=128, name="long sentences B=64 x L=128 (BASELINE configs[2])")}
+           2: dict(B=64, L=128, name="long sentences B=64 x L=128 (BASELINE configs[2])"),
+           # SURVEY §8d config 3, scaled to a sample: ragged lengths, length-bucketed batches of <= 8192 tokens
+           3: dict(B=None, L=None, n_sent=4096, name="ragged corpus L~clip(N(22,10),3,80), bucketed <=8192 tokens "
+                                                        "(SURVEY 8d config 3, 4096-sentence sample per rank)")}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
@@ -51,6 +54,15 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision):
     p.to(device)
     col = MorphoCollate(enc)
     batches, docs = [], []
+    if cfg_id == 3:
+        from cube_amd.sharding import bucketed_batches
+        rng = np.random.default_rng(3000 + rank)
+        lens = np.clip(np.round(rng.normal(22, 10, size=c["n_sent"])), 3, 80).astype(np.int64)
+        doc = synth.make_document(enc, lens, seed=3000 + rank, ext_word_emb=(300,))
+        for idx in bucketed_batches(lens, 8192):
+            X = col.collate_fn([doc.sentences[i] for i in idx], targets=False)
+            batches.append(p._prepare(X))
+        return p, cfg, enc, sd, batches, [doc]
     for i in range(n_batches):
         doc = synth.make_document(enc, [c["L"]] * c["B"], seed=1000 * (rank + 1) + i, ext_word_emb=(300,))
         X = col.collate_fn(doc.sentences)
@@ -153,7 +165,10 @@ def main():
             td.destroy_process_group()
         return
 
-    sent_per_s = args.steps * c["B"] * world / dt
+    if args.config == 3:  # steps cycle through the bucketed batches: count the sentences actually processed
+        sent_per_s = sum(batches[i % len(batches)]["B"] for i in range(args.steps)) * world / dt
+    else:
+        sent_per_s = args.steps * c["B"] * world / dt
     # ---- roofline of the dominant kernel: char-CNN gated conv GEMM, layers >= 1
     bt = batches[0]
     NW = bt["N"] * bt["W"]
@@ -189,7 +204,7 @@ def main():
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(cfg, enc, sd, docs, 32 if args.config == 1 else 8)
+        out["cpu_baseline"] = cpu_baseline(cfg, enc, sd, docs, {1: 32, 2: 8, 3: 32}[args.config])
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -610,16 +610,12 @@ class Parser(_HipNet):
             for w, h, l, u, x, a in zip(s.words, heads[b], lab[b], up[b], xp[b], at[b]):
                 w.head, w.label, w.upos, w.xpos, w.attrs = h, l, u, x, a
 
-    def process(self, doc, collate, batch_size=4, num_workers=4):
-        """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
-        head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
-        two deep (featurisation and write-back of neighbours overlap the GPU)."""
-        self.eval()
-        self._require_gpu()
-        sents = doc.sentences
+    def _run_batches(self, batches, collate=None):
+        """batches: iterable of (list of Sentence, position label for error messages); two deep in
+        flight; results are written into the Sentence objects."""
+        collate = collate or self._collate
         pending = None
-        for start in range(0, len(sents), batch_size):
-            batch = sents[start:start + batch_size]
+        for batch, start in batches:
             X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
             X.pop("y_upos", None)
             ticket = self.submit(self._prepare(X))
@@ -628,4 +624,29 @@ class Parser(_HipNet):
             pending = (batch, start, ticket)
         if pending is not None:
             self._write_back(pending[0], pending[1], *self.collect(pending[2]))
+
+    def process_bucketed(self, doc, collate, max_tokens=8192):
+        """Throughput mode for ragged documents: sentences sorted by length and
+        packed into batches of at most `max_tokens` padded positions, results written back in place.
+        NOT the reference's batch composition: scores differ from `process` in the way the
+        reference's own scores differ between batch sizes (padding is visible to its convolutions
+        and BiLSTM)."""
+        from cube_amd.sharding import bucketed_batches
+        self.eval()
+        self._require_gpu()
+        self._collate = collate
+        sents = doc.sentences
+        groups = bucketed_batches([len(s.words) for s in sents], max_tokens)
+        self._run_batches(([sents[i] for i in idx], int(idx[0])) for idx in groups)
+        return doc
+
+    def process(self, doc, collate, batch_size=4, num_workers=4):
+        """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
+        head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
+        two deep (featurisation and write-back of neighbours overlap the GPU)."""
+        self.eval()
+        self._require_gpu()
+        self._collate = collate
+        sents = doc.sentences
+        self._run_batches((sents[start:start + batch_size], start) for start in range(0, len(sents), batch_size))
         return doc

@@ -19,6 +19,22 @@ def shard_bounds(n_sentences, rank, world_size, batch_size):
     return min(first * batch_size, n_sentences), min((first + count) * batch_size, n_sentences)
 
 
+def bucketed_batches(sent_lens, max_tokens=8192, max_sentences=1024):
+    """Length-bucketed batches: sentence indices sorted by length (stable), cut greedily so that
+    sentences x longest length <= max_tokens.  -> list of index arrays (each sorted by length)."""
+    import numpy as np
+    lens = np.asarray(sent_lens, dtype=np.int64)
+    order = np.argsort(lens, kind="stable")
+    out, start = [], 0
+    while start < len(order):
+        end = start + 1
+        while end < len(order) and end - start < max_sentences and (end - start + 1) * int(lens[order[end]]) <= max_tokens:
+            end += 1
+        out.append(order[start:end])
+        start = end
+    return out
+
+
 class _Slice:
     """A view of a Document holding only sentences[lo:hi] (same Sentence objects)."""
 

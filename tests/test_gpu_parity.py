@@ -540,3 +540,28 @@ def test_process_edge_documents(dev):
         assert len(got) == len(exp)
         diff = sum(x != y for x, y in zip(got, exp))
         assert diff <= max(1, len(got) // 100), (diff, len(got))  # random-init margins: allow a near-tie flip
+
+
+def test_process_bucketed_writes_back_in_place(dev):
+    """process_bucketed with one bucket = process on the length-sorted document with one batch:
+    same batch composition, so the same strings must land on the same Sentence objects."""
+    from cube_amd import synth
+    from cube_amd.io_utils.objects import Document
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    col = MorphoCollate(enc)
+    a = cases.document(case, enc, "g6")
+    b = cases.document(case, enc, "g6")
+    p.process_bucketed(a, col, max_tokens=1 << 20)
+    order = np.argsort([len(s.words) for s in b.sentences], kind="stable")
+    srt = Document()
+    srt.sentences = [b.sentences[i] for i in order]
+    p.process(srt, col, batch_size=len(order))
+    assert str(a) == str(b)
+    # many small buckets: every word gets filled, trees stay valid
+    c = cases.document(case, enc, "g6")
+    p.process_bucketed(c, col, max_tokens=64)
+    for s in c.sentences:
+        assert _is_single_rooted_tree(np.array([int(w.head) for w in s.words]))
+        assert all(w.upos != "_" and w.label != "_" for w in s.words)

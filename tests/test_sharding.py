@@ -60,3 +60,18 @@ def test_two_rank_gloo_run_equals_single_process(tmp_path):
     doc = synth.make_document(enc, [3 + (i * 7) % 11 for i in range(37)], seed=5, ext_word_emb=(4,))
     _FakeParser().process(doc, None, batch_size=4)
     assert open(out, encoding="utf-8").read() == str(doc)
+
+
+def test_bucketed_batches_cover_every_sentence_within_the_token_budget():
+    import numpy as np
+    from cube_amd.sharding import bucketed_batches
+    rng = np.random.default_rng(2)
+    lens = np.clip(np.round(rng.normal(22, 10, size=3000)), 3, 80).astype(np.int64)
+    groups = bucketed_batches(lens, max_tokens=8192)
+    seen = np.concatenate(groups)
+    assert sorted(seen.tolist()) == list(range(len(lens)))
+    for g in groups:
+        assert len(g) * int(lens[g].max()) <= 8192 and len(g) <= 1024
+        assert (np.diff(lens[g]) >= 0).all()
+    assert bucketed_batches([], 8192) == []
+    assert [g.tolist() for g in bucketed_batches([9000, 2], 8192)] == [[1], [0]]  # an over-long sentence still gets a batch
