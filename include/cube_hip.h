@@ -14,6 +14,7 @@
  *   cube_gather_rows        nn.Embedding lookups + torch.cat (modules.py:451-457;
  *                           parser.py:140-154), unpack() (utils.py:17-32)
  *   cube_masked_mean        WordGram masked mean (modules.py:480-483)
+ *   cube_char_conv0_lookup  WordGram embeddings + first ConvNorm/BatchNorm/gate (modules.py:451-472)
  *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197; tagger.py:118-119)
  *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
  *   cube_bilstm_recurrent   torch.lstm recurrence, 1 layer, both directions (parser.py:201)
@@ -119,6 +120,20 @@ int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, c
 int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                      int ld_x, const int32_t* len, int N, int W, int C,
                      void* out, void* out_lo, int ld_out, const int32_t* word_rows, void* stream);
+
+/* First gated layer of the character CNN as table look-ups (modules.py:451-455,462-472): its input
+ * at a position is [tok_emb[char] | case_emb[case] | lang_emb[lang]], so the Conv1d(k=taps) + BN
+ * pre-activation of a position is  sum over the taps inside the word of
+ *   T[tap][cc[input row]][:]          T f32 [taps, n_combo, 2*half] = W_tap . [tok_emb | case_emb] per
+ *                                     (character, case) combination, columns [tanh half | sigmoid half]
+ * + btab[lang_word[word]][tap mask][:]  (bias + language channels, as bias_tab above, same column order)
+ * and the output is tanh(.)*sigmoid(.) as bf16 hi (+ lo) rows [row, 0..half).  Rows follow `groups`
+ * (cube_conv_groups of layer 0: cc is indexed by INPUT row, the output rows of the groups must be
+ * contiguous from 0).  HBM/L2-bound (taps + 1 table rows per position) instead of an MFMA GEMM
+ * over K = taps * (char_emb + case_emb).                                                         */
+int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                           const cube_conv_groups* groups, int taps, int half, int n_combo,
+                           void* out, void* out_lo, int ld_out, void* stream);
 
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
  * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 5; }
+extern "C" int cube_abi_version(void) { return 6; }
 
 namespace {
 
@@ -155,6 +155,51 @@ __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int l
   if (db_lo) db_lo[orow * ld_b + col_b + c] = vl;
 }
 
+// ---- first gated character layer as table look-ups (see cube_char_conv0_lookup in the header)
+__global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restrict__ T, const float* __restrict__ btab,
+                                                           const int32_t* __restrict__ cc, const int32_t* __restrict__ lang_word,
+                                                           const cube_conv_groups cg, int taps, int half, int n_combo,
+                                                           uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, int ld_out,
+                                                           int tpr, int rpb, int total_rows) {
+  const int r_local = threadIdx.x / tpr;
+  const int row = blockIdx.x * rpb + r_local;
+  if (r_local >= rpb || row >= total_rows) return;
+  const int c4 = (threadIdx.x - r_local * tpr) * 4;
+  int g = 0;
+  for (; g < cg.n - 1; ++g)
+    if (row < cg.row0_out[g] + cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g]) break;
+  const int seq_in = cg.seq_in[g], seq_out = cg.seq_out[g];
+  const int rel = row - cg.row0_out[g];
+  const int j = rel / seq_out, pos = rel - j * seq_out;
+  const int in0 = cg.row0_in[g] + j * seq_in + pos - (taps >> 1);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  unsigned mask = 0;
+  const size_t F = 2 * (size_t)half;
+  for (int t = 0; t < taps; ++t) {
+    const int pp = pos + t - (taps >> 1);
+    if (pp < 0 || pp >= seq_in) continue;
+    mask |= 1u << t;
+    const float* tp = T + ((size_t)t * n_combo + cc[in0 + t]) * F + c4;
+    const float4 va = *reinterpret_cast<const float4*>(tp);
+    const float4 vb = *reinterpret_cast<const float4*>(tp + half);
+    a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+    b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+  }
+  const float* bp = btab + ((size_t)lang_word[cg.word0[g] + j] * 32 + mask) * F + c4;
+  const float4 ba = *reinterpret_cast<const float4*>(bp);
+  const float4 bb = *reinterpret_cast<const float4*>(bp + half);
+  const float gv[4] = {tanhf_(a.x + ba.x) * sigmoidf_(b.x + bb.x), tanhf_(a.y + ba.y) * sigmoidf_(b.y + bb.y),
+                       tanhf_(a.z + ba.z) * sigmoidf_(b.z + bb.z), tanhf_(a.w + ba.w) * sigmoidf_(b.w + bb.w)};
+  uint16_t h[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (out_lo) split_bf16(gv[k], h[k], l[k]); else h[k] = f32_to_bf16(gv[k]);
+  }
+  const size_t o = (size_t)row * ld_out + c4;
+  *reinterpret_cast<uint2*>(out + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  if (out_lo) *reinterpret_cast<uint2*>(out_lo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
 // ---- arg-max (first maximal index, like torch.argmax / numpy.argmax): one wave per row
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld, int col0, int n, int M, int32_t* out) {
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -237,6 +282,32 @@ extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int r
                      root, P, (float)K, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
                      (uint16_t*)dst_b_lo, ld_b, col_b);
   CUBE_CHECK_LAUNCH("cube_ext_finish");
+  return CUBE_OK;
+}
+
+extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                                      const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                                      void* out_lo, int ld_out, void* stream) {
+  if (!T || !btab || !cc || !lang_word || !groups || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: null pointer");
+  if ((taps != 1 && taps != 3 && taps != 5) || half <= 0 || half % 4 || half > 1024 || n_combo <= 0 || ld_out < half || ld_out % 4)
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: bad taps / half / ld_out");
+  if ((uintptr_t)T % 16 || (uintptr_t)btab % 16 || (uintptr_t)out % 8 || (uintptr_t)out_lo % 8)
+    CUBE_FAIL(CUBE_ERR_ALIGN, "cube_char_conv0_lookup: tables must be 16-byte aligned, outputs 8-byte aligned");
+  const cube_conv_groups& cg = *groups;
+  if (cg.n <= 0 || cg.n > CUBE_MAX_CONV_GROUPS) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: %d sequence groups", cg.n);
+  int total = 0;
+  for (int g = 0; g < cg.n; ++g) {
+    if (cg.seq_in[g] <= 0 || cg.n_rows[g] <= 0 || cg.n_rows[g] % cg.seq_in[g] || cg.seq_out[g] <= 0 ||
+        cg.seq_out[g] > cg.seq_in[g] || cg.row0_out[g] != total || cg.row0_in[g] < 0 || cg.word0[g] < 0)
+      CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: bad sequence group %d (output rows must be contiguous)", g);
+    total += cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+  }
+  const int tpr = half / 4;
+  const int rpb = tpr >= 256 ? 1 : 256 / tpr;
+  if (tpr > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: half=%d too wide", half);
+  hipLaunchKernelGGL(conv0_lookup_kernel, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
+                     lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
+  CUBE_CHECK_LAUNCH("cube_char_conv0_lookup");
   return CUBE_OK;
 }
 

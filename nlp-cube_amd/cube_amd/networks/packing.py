@@ -101,6 +101,38 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None):
     return out
 
 
+def pack_conv0_tables(sd, prefix, tok_emb, case_emb, lang_emb, max_bytes=64 << 20):
+    """First gated char layer as table look-ups.  Its input at a position is an embedding look-up
+    [tok_emb[c] | case_emb[k] | lang_emb[g]] (modules.py:451-455,470), so the Conv1d pre-activation
+    is a sum of per-(tap, character, case) vectors:
+      T[t][c*n_case + k][:] = W[:, tok channels, t] @ tok_emb[c] + W[:, case channels, t] @ case_emb[k]
+    plus the (language, tap mask) bias table of `pack_gated_conv`.  Columns are laid out
+    [tanh half | sigmoid half] in channel order.  fp64 -> fp32; `*_q` from bf16-rounded operands
+    (single-pass contract).  Returns None when the tables would exceed max_bytes or half % 4 != 0."""
+    w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
+    b = sd[prefix + ".0.conv.bias"].float()
+    s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
+    w = w * s[:, None, None]
+    b = (b - sd[prefix + ".1.running_mean"].float()) * s + sd[prefix + ".1.bias"].float()
+    F_, cin, taps = w.shape
+    half = F_ // 2
+    n_char, ce = tok_emb.shape
+    n_case, ke = case_emb.shape
+    if half % 4 or taps > 5 or taps * n_char * n_case * F_ * 4 > max_bytes:
+        return None
+    out = dict(taps=taps, half=half, n_case=n_case, n_combo=n_char * n_case)
+    for sfx, q in (("", lambda t: t.double()), ("_q", lambda t: t.to(torch.bfloat16).double())):
+        tt = torch.einsum("ce,fet->tcf", q(tok_emb.float()), q(w[:, :ce, :]))                 # [taps, n_char, F]
+        tc = torch.einsum("ke,fet->tkf", q(case_emb.float()), q(w[:, ce:ce + ke, :]))          # [taps, n_case, F]
+        T = (tt[:, :, None, :] + tc[:, None, :, :]).reshape(taps, n_char * n_case, F_)
+        contrib = torch.einsum("gc,fct->gtf", q(lang_emb.float()), q(w[:, ce + ke:, :]))        # [G, taps, F]
+        masks = torch.tensor([[(m >> t) & 1 for t in range(taps)] for m in range(32)], dtype=torch.float64)
+        bt = torch.einsum("mt,gtf->gmf", masks, contrib) + b.double()[None, None, :]            # [G, 32, F]
+        out["T" + sfx] = T.float().contiguous()
+        out["btab" + sfx] = bt.float().contiguous()
+    return out
+
+
 def pack_linear(w, b, in_perm=None, out_rows=None, n_pad=None):
     """w [n_out, n_in] -> W bf16 [pad128(rows), pad32(cols)], bias f32.
     in_perm: buffer column -> reference input feature (-1 = zero column);
@@ -178,6 +210,8 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
         pk["char_convs"].append(pack_gated_conv(sd, "_word_net._convolutions_char.%d" % l, np.arange(cin),
                                                 double_first=lay.char_half if l > 0 else 0,
                                                 bcast=(cin + np.arange(lay.lang), wn_lang)))
+    pk["char_l0"] = pack_conv0_tables(sd, "_word_net._convolutions_char.0", sd["_word_net._tok_emb.weight"],
+                                      sd["_word_net._case_emb.weight"], wn_lang)
     pk["char_pre_out"] = pack_linear(sd["_word_net._pre_out.linear_layer.weight"], sd["_word_net._pre_out.linear_layer.bias"])
     pk["ext"] = []
     for i, e in enumerate(ext_dims):
@@ -318,9 +352,10 @@ def to_device(obj, device, with_lo=True):
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
     if isinstance(obj, dict):
-        out = {k: to_device(v, device, with_lo) for k, v in obj.items() if k != "bias_tab_q"}
-        if "bias_tab_q" in obj and not with_lo:
-            out["bias_tab"] = obj["bias_tab_q"].to(device)
+        out = {k: to_device(v, device, with_lo) for k, v in obj.items() if k not in ("bias_tab_q", "T_q", "btab_q")}
+        for k in ("bias_tab", "T", "btab"):  # single-pass bf16: the tables built from bf16-rounded operands
+            if k + "_q" in obj and not with_lo:
+                out[k] = obj[k + "_q"].to(device)
         return out
     if isinstance(obj, list):
         return [to_device(v, device, with_lo) for v in obj]

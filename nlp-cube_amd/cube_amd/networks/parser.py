@@ -16,6 +16,8 @@ launches on the current HIP stream, 1 download of five int32 arrays — the refe
 mid-batch syncs (parser.py:125, 425, 428-431) are gone because unpack, soft-max, MST decoding
 and the head gather for label scoring all stay on the device.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -178,6 +180,9 @@ class _HipNet:
         x_case = X["x_word_case"].cpu().numpy()
         char_idx = np.concatenate([x_word[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
         case_idx = np.concatenate([x_case[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
+        l0 = self._pk.get("char_l0")
+        if l0 is not None:  # layer 0 by table look-up: one (character, case) combination id per position
+            char_idx, case_idx = char_idx * l0["n_case"] + case_idx, np.zeros(0, dtype=np.int64)
         parts = [
             char_idx, case_idx, X["x_lang_word"].cpu().numpy()[order], X["x_word_len"].cpu().numpy()[order],
             (sb * T + si + root)[order], word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
@@ -273,16 +278,28 @@ class _HipNet:
 
         # ---- character level, in ragged per-length layouts (`_char_layout`)
         rows = bt["char_rows"]
-        xc0 = buf.get("xc0", rows[0], lay.xc0_w)
-        gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, rows[0])
-        gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, rows[0])
+        l0 = pk.get("char_l0")
         nchar = len(pk["char_convs"])
+        if l0 is None:
+            xc0 = buf.get("xc0", rows[0], lay.xc0_w)
+            gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, rows[0])
+            gather(xc0, lay.xc0_w, lay.char_emb, lay.case_emb, pk["case_emb"], bt["case_idx"], None, rows[0])
         # every gated layer keeps its own output g_l: the next layer reads it, and the masked mean
         # sums them (no fp32 residual stream through HBM at N*W rows).  The language channels are
         # not materialised: they enter through the per-(language, tap mask) bias table.
         gl = [buf.get("xc_g%d" % l, rows[l + 1], lay.xc_w) for l in range(nchar)]
-        src, src_ld = xc0, lay.xc0_w
+        src, src_ld = (xc0, lay.xc0_w) if l0 is None else (None, 0)
         for l, cv in enumerate(pk["char_convs"]):
+            if l == 0 and l0 is not None:
+                # embeddings + first gated layer as table look-ups (cube_char_conv0_lookup): HBM/L2-bound
+                # instead of a K = 5*288 GEMM over every character position
+                with self._timed("char_conv0"):
+                    hip.check(lib.cube_char_conv0_lookup(l0["T"].data_ptr(), l0["btab"].data_ptr(), bt["char_idx"].data_ptr(),
+                                                         bt["lang_word"].data_ptr(), ctypes.pointer(bt["conv_groups"][0]),
+                                                         l0["taps"], l0["half"], l0["n_combo"], gl[0].hi.data_ptr(),
+                                                         lo(gl[0].lo), lay.xc_w, st), "cube_char_conv0_lookup")
+                src, src_ld = gl[0], lay.xc_w
+                continue
             with self._timed("char_conv" if l > 0 else "char_conv0"):
                 hip.gemm(src, src_ld, rows[l], cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
                          ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"],

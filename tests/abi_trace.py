@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 5
+        return 6
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -149,6 +149,26 @@ class TraceLib:
                 self._need("masked_mean x_lo[%d]" % k, x_lo[k], 2 * (last * ld_x + C), 2)
         for nm, p in (("out", out), ("out_lo", out_lo)):
             self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
+        return 0
+
+    def cube_char_conv0_lookup(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream):
+        cg = groups.contents
+        self.calls.append(("conv0_lookup", cg.n, half))
+        assert taps in (1, 3, 5) and half % 4 == 0 and ld_out >= half and 1 <= cg.n <= 32
+        total = n_in = n_words = 0
+        for g in range(cg.n):
+            assert cg.n_rows[g] % cg.seq_in[g] == 0 and 0 < cg.seq_out[g] <= cg.seq_in[g] and cg.row0_out[g] == total
+            nw = cg.n_rows[g] // cg.seq_in[g]
+            total += nw * cg.seq_out[g]
+            n_in = max(n_in, cg.row0_in[g] + cg.n_rows[g])
+            n_words = max(n_words, cg.word0[g] + nw)
+        ids = self._ints("conv0 cc", cc, n_in)
+        assert ids.min() >= 0 and ids.max() < n_combo
+        lw = self._ints("conv0 lang_word", lang_word, n_words)
+        self._need("conv0 T", T, 4 * taps * n_combo * 2 * half, 16)
+        self._need("conv0 btab", btab, 4 * (int(lw.max()) + 1) * 32 * 2 * half, 16)
+        for nm, p in (("out", out), ("out_lo", out_lo)):
+            self._need("conv0 " + nm, p, 2 * ((total - 1) * ld_out + half), 8)
         return 0
 
     def cube_ext_finish(self, acc, ld_acc, B, L, root, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):
