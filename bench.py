@@ -177,7 +177,7 @@ def main():
     # algorithmic (what the reference computes, SURVEY §8d F_char): 2 * N*W rows * 5 taps * (256+64) * 512
     flops_per_launch = 2.0 * NW * 5 * kc * nf
     # executed by this implementation: ragged rows, language channels folded into the bias table, 3 bf16 passes
-    rows_exec = float(np.mean(bt["char_rows"][1:len(bt["char_rows"]) - 1]))
+    rows_exec = float(np.mean(bt["char_rows"][2:]))  # output rows of layers >= 1 (tiles run over output rows)
     passes = 3 if p.precision == "bf16x3" else 1
     flops_executed = 2.0 * rows_exec * 5 * lay.char_half * nf * passes
     ms = kt["ms_mean"]
