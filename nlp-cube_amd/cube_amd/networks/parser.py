@@ -121,6 +121,7 @@ class _HipNet:
             self._split = self.precision == "bf16x3"
             self._pk = packing.to_device(self._pk_cpu, device, with_lo=self._split)
             self._buf = _Buffers(device, self._split)
+            self._layouts = {}
             self._buf.streams = self._streams or ()
         return self
 
@@ -311,7 +312,10 @@ class _HipNet:
                         word_rows=bt["word_rows"], stream=st)
         # ---- word level input XW0 = [word | char | lang | ext] (+ root row = _r_emb for the parser)
         xw0 = buf.get("xw0", BT, lay.xw0_w)
-        self._zero(xw0, BT * lay.xw0_w)
+        if N != BL:
+            # pad positions keep a zero char-level vector (unpack, utils.py:17-32); every other element
+            # of XW0 is rewritten below for every row.  Without pads nothing needs clearing.
+            self._zero(xw0, BT * lay.xw0_w)
         gather(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT)
         po = pk["char_pre_out"]
         hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
@@ -411,7 +415,13 @@ class Parser(_HipNet):
         # XL0 = [x_parse | lang | ext] (LSTM input), XM = [hidden | lang] (morphology input)
         xl0_w = p32(wh + lg + P)
         xl0 = buf.get("xl0_%d" % slot, BT, xl0_w)
-        self._zero(xl0, BT * xl0_w)
+        # XL0: x_parse, lang and ext columns are rewritten for every word row each batch; only the ext
+        # columns of the root rows must read zero (parser.py:195-197), and they do as long as the
+        # (B, T) layout of this slot's buffer has not changed since it was last cleared
+        lay_key = "xl0_layout_%d" % slot
+        if getattr(self, "_layouts", {}).get(lay_key) != (bt["B"], bt["T"]):
+            self._zero(xl0, BT * xl0_w)
+            self._layouts = dict(getattr(self, "_layouts", {}), **{lay_key: (bt["B"], bt["T"])})
         xm_w = p32(wh + lg)
         xm = buf.get("xm", BT, xm_w)
         out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,
