@@ -85,6 +85,7 @@ class _HipNet:
         self.precision = "bf16x3"  # or "bf16"; set before .to(device)
         self._timing = None
         self._streams = None
+        self._layouts = {}
 
     # ---- reference-compatible module surface ----------------------------------------------
     def eval(self):
@@ -419,9 +420,9 @@ class Parser(_HipNet):
         # columns of the root rows must read zero (parser.py:195-197), and they do as long as the
         # (B, T) layout of this slot's buffer has not changed since it was last cleared
         lay_key = "xl0_layout_%d" % slot
-        if getattr(self, "_layouts", {}).get(lay_key) != (bt["B"], bt["T"]):
+        if self._layouts.get(lay_key) != (bt["B"], bt["T"]):
             self._zero(xl0, BT * xl0_w)
-            self._layouts = dict(getattr(self, "_layouts", {}), **{lay_key: (bt["B"], bt["T"])})
+            self._layouts[lay_key] = (bt["B"], bt["T"])
         xm_w = p32(wh + lg)
         xm = buf.get("xm", BT, xm_w)
         out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,

@@ -60,24 +60,46 @@ class Tagger(_HipNet):
         return r
 
     def process(self, doc, collate, upos=True, xpos=True, attrs=True, batch_size=32, num_workers=4):
-        """reference: tagger.py:288-329 — in-order batches; fills upos / xpos / attrs of every word."""
+        """reference: tagger.py:288-329 — in-order batches; fills upos / xpos / attrs of every word.
+        The ids of a batch come back through pinned memory by an asynchronous copy, so the host
+        prepares batch i+1 and writes batch i-1 back while the GPU works on batch i."""
         self.eval()
         if not (upos or xpos or attrs):
             raise Exception("To perform tagging at least one of 'upos', 'xpos' or 'attrs' must be set to True.")
         self._require_gpu()
         enc = self._encodings
+        tabs = tuple(np.asarray(t, dtype=object) for t in (enc.upos_list, enc.xpos_list, enc.attrs_list))
+        host = [None, None]
+
+        def write_back(batch, h, done, B, L):
+            done.synchronize()
+            res = h[:3 * B * L].view(3, B, L).numpy()
+            up, xp, at = tabs[0][res[0]], tabs[1][res[1]], tabs[2][res[2]]
+            for b, s in enumerate(batch):
+                for w, u, x, a in zip(s.words, up[b], xp[b], at[b]):
+                    if upos:
+                        w.upos = u
+                    if xpos:
+                        w.xpos = x
+                    if attrs:
+                        w.attrs = a
+
         sents = doc.sentences
-        for start in range(0, len(sents), batch_size):
+        pending = None
+        for k, start in enumerate(range(0, len(sents), batch_size)):
             batch = sents[start:start + batch_size]
             X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
             X.pop("y_upos", None)
-            res = self.tag_batch(X)["packed"].cpu().numpy()
-            for b, s in enumerate(batch):
-                for i, w in enumerate(s.words):
-                    if upos:
-                        w.upos = enc.upos_list[res[0, b, i]]
-                    if xpos:
-                        w.xpos = enc.xpos_list[res[1, b, i]]
-                    if attrs:
-                        w.attrs = enc.attrs_list[res[2, b, i]]
+            packed = self.tag_batch(X)["packed"]
+            _, B, L = packed.shape
+            if host[k % 2] is None or host[k % 2].numel() < packed.numel():
+                host[k % 2] = torch.empty(packed.numel(), dtype=torch.int32, pin_memory=True)
+            host[k % 2][:packed.numel()].view(3, B, L).copy_(packed, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            if pending is not None:
+                write_back(*pending)
+            pending = (batch, host[k % 2], done, B, L)
+        if pending is not None:
+            write_back(*pending)
         return doc
