@@ -40,3 +40,20 @@ __device__ __forceinline__ float tanhf_(float x) {
   const float e = __expf(2.0f * x);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember per
+// device (one process may drive several GPUs) what has been reserved for a kernel.
+constexpr int CUBE_MAX_DEVICES = 64;
+struct CubeLdsReservation {
+  size_t bytes[CUBE_MAX_DEVICES] = {};
+  // true if `lds` bytes are (now) reserved for `fn` on the current device
+  bool ensure(const void* fn, size_t lds) {
+    if (lds <= 65536) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CUBE_MAX_DEVICES) return false;
+    if (bytes[dev] >= lds) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    bytes[dev] = lds;
+    return true;
+  }
+};

@@ -441,13 +441,9 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 template <int EPI, bool SPLIT, class C>
 int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_kernel<EPI, SPLIT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
-    attr_set = true;
-  }
+  static CubeLdsReservation reserved;
+  if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C>, lds))
+    CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
   p.n_tiles = p.N / C::BN;
   p.m_tiles = (p.M + C::BM - 1) / C::BM;
   if (cg.n > 0) {

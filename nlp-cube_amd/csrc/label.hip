@@ -144,22 +144,16 @@ int launch_label(bool split, dim3 grid, hipStream_t st, const uint16_t* hl, cons
                  const int32_t* heads, const int32_t* lens, int B, int L, float* logits) {
   if (split) {
     constexpr int lds = LabelCfg<QT, true>::LDS;
-    static bool set = false;
-    if (!set && lds > 65536) {
-      if (hipFuncSetAttribute((const void*)label_kernel<QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_label_score: cannot reserve %d bytes of LDS", lds);
-      set = true;
-    }
+    static CubeLdsReservation reserved;
+    if (!reserved.ensure((const void*)label_kernel<QT, true>, lds))
+      CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_label_score: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((label_kernel<QT, true>), grid, dim3(256), lds, st, hl, hl_lo, ld_hl, col_x2, wl, wl_lo, bias,
                        n_labels, per, heads, lens, B, L, logits);
   } else {
     constexpr int lds = LabelCfg<QT, false>::LDS;
-    static bool set = false;
-    if (!set && lds > 65536) {
-      if (hipFuncSetAttribute((const void*)label_kernel<QT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_label_score: cannot reserve %d bytes of LDS", lds);
-      set = true;
-    }
+    static CubeLdsReservation reserved;
+    if (!reserved.ensure((const void*)label_kernel<QT, false>, lds))
+      CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_label_score: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((label_kernel<QT, false>), grid, dim3(256), lds, st, hl, hl_lo, ld_hl, col_x2, wl, wl_lo, bias,
                        n_labels, per, heads, lens, B, L, logits);
   }

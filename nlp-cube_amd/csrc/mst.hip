@@ -530,16 +530,11 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
   hipStream_t st = (hipStream_t)stream;
   const bool gs = L + 1 > MST_MAX_N;
   const size_t lds = mst_lds_bytes(L + 1, gs);
-  static size_t lds_set[4] = {0, 0, 0, 0};
+  static CubeLdsReservation reserved[4];
   const void* fns[4] = {(const void*)mst_first_kernel<false>, (const void*)mst_root_kernel<false>,
                         (const void*)mst_first_kernel<true>, (const void*)mst_root_kernel<true>};
-  for (int k = gs ? 2 : 0; k < (gs ? 4 : 2); ++k) {
-    if (lds > 65536 && lds > lds_set[k]) {
-      if (hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
-      lds_set[k] = lds;
-    }
-  }
+  for (int k = gs ? 2 : 0; k < (gs ? 4 : 2); ++k)
+    if (!reserved[k].ensure(fns[k], lds)) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
   MstWs ws = mst_ws_carve(workspace, B, L);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
   int nblk = B * L;
