@@ -565,3 +565,35 @@ def test_process_bucketed_writes_back_in_place(dev):
     for s in c.sentences:
         assert _is_single_rooted_tree(np.array([int(w.head) for w in s.words]))
         assert all(w.upos != "_" and w.label != "_" for w in s.words)
+
+
+def test_cube_api_loads_model_files_and_parses(dev, tmp_path):
+    """CubeObj (reference cube/api.py:39-128) from a model directory in the reference's on-disk
+    formats — tokenizer .yaml (flavours), parser .config (INI), .encodings, Lightning-style .best —
+    gives the same Document as Parser.process on the same weights; unknown flavour and raw text
+    raise like the reference / as documented."""
+    import yaml
+    from cube_amd.api import CubeObj
+    from cube_amd.networks.lm import LMHelperPrecomputed
+    from cube_amd.networks.utils import MorphoCollate
+    from cube_amd import synth
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    base = str(tmp_path / "en")
+    with open(base + "-trf-tokenizer.yaml", "w") as f:
+        yaml.safe_dump({"language_codes": synth.EN_LANGUAGE_CODES, "language_map": {"en": synth.EN_LANGUAGE_CODES[3]}}, f)
+    cfg.save(base + "-trf-parser.config")
+    enc.save(base + "-trf-parser.encodings")
+    torch.save({"state_dict": sd, "epoch": 3}, base + "-trf-parser.best")
+    cube = CubeObj(base, device=str(dev), lang="en", lm_helper=LMHelperPrecomputed(list(case["ext"])))
+    a = cases.document(case, enc, "g6")
+    b = cases.document(case, enc, "g6")
+    out = cube(a)
+    assert out is a
+    p, _, _, _ = _model(dev, case, "bf16x3")
+    p.process(b, MorphoCollate(enc), num_workers=0)
+    assert str(a) == str(b)
+    with pytest.raises(Exception, match="Unsupported language flavour"):
+        cube(a, flavour="xx_unknown")
+    with pytest.raises(NotImplementedError):
+        cube("raw text needs the tokenizer")
