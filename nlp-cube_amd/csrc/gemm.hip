@@ -34,6 +34,11 @@ constexpr int ROWB = 64;  // bytes per LDS row (32 bf16); 16-byte chunks XOR-swi
 // the slab is made as large as the 160 KiB of LDS allow and a tile takes fewer rows if it must.
 struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, SR = 352; };
 struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, SR = 176; };
+// Shorter variant of the big tile (8 waves, 96x64 per wave).  A launch of T equal tiles on 256 CUs
+// at one block per CU takes ceil(T/256) rounds: when the last round of 256-row tiles would be mostly
+// empty, more, shorter tiles finish sooner (see `launch_split`; a 128-row variant lost what it
+// gained to its lower per-tile efficiency and was dropped).
+struct CfgBig192 { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 272; };
 
 constexpr int MAX_TAPS = 5;
 template <class C> constexpr int slab_rows() { return C::SR; }
@@ -438,6 +443,19 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   }
 }
 
+// row tiles of a launch with tile height BM / slab SR (-1: a sequence does not fit the slab)
+inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR) {
+  if (cg.n <= 0) return (M + BM - 1) / BM;
+  int tiles = 0;
+  for (int g = 0; g < cg.n; ++g) {
+    const int bm = tile_rows(BM, SR, cg.seq_in[g], cg.seq_out[g]);
+    if (bm < 1) return -1;
+    const int n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+    tiles += (n_out + bm - 1) / bm;
+  }
+  return tiles;
+}
+
 template <int EPI, bool SPLIT, class C>
 int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
@@ -445,27 +463,35 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C>, lds))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
   p.n_tiles = p.N / C::BN;
-  p.m_tiles = (p.M + C::BM - 1) / C::BM;
-  if (cg.n > 0) {
-    p.m_tiles = 0;
-    for (int g = 0; g < cg.n; ++g) {
-      const int bm = tile_rows(C::BM, C::SR, cg.seq_in[g], cg.seq_out[g]);
-      if (bm < 1) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: sequences of %d rows do not fit the activation slab", cg.seq_in[g]);
-      const int n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
-      p.m_tiles += (n_out + bm - 1) / bm;
-    }
-  }
+  p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR);
+  if (p.m_tiles < 0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: a sequence group does not fit the activation slab");
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
   hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
   return CUBE_OK;
 }
 
+constexpr int NUM_CUS = 256;
+
+template <int EPI, bool SPLIT>
+int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
+  // the big tiles need enough row tiles to fill the 256 CUs
+  const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
+  if (!big) return launch_cfg<EPI, SPLIT, CfgSmall>(p, cg, st);
+  // one block per CU: time ~ rounds x tile height (x a small penalty for the shorter tiles, whose
+  // weight-tile traffic and fragment reads are spread over fewer rows)
+  const long nt = p.N / CfgBig::BN;
+  auto cost = [&](int BM, int SR, double penalty) {
+    const int t = count_row_tiles(p.M, cg, BM, SR);
+    return t < 0 ? 1e30 : (double)((t * nt + NUM_CUS - 1) / NUM_CUS) * BM * penalty;
+  };
+  if (cost(CfgBig192::BM, CfgBig192::SR, 1.04) < cost(CfgBig::BM, CfgBig::SR, 1.0))
+    return launch_cfg<EPI, SPLIT, CfgBig192>(p, cg, st);
+  return launch_cfg<EPI, SPLIT, CfgBig>(p, cg, st);
+}
+
 template <int EPI>
 int launch(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
-  // the big tile needs enough row tiles to fill the 256 CUs
-  const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
-  if (p.A_lo) return big ? launch_cfg<EPI, true, CfgBig>(p, cg, st) : launch_cfg<EPI, true, CfgSmall>(p, cg, st);
-  return big ? launch_cfg<EPI, false, CfgBig>(p, cg, st) : launch_cfg<EPI, false, CfgSmall>(p, cg, st);
+  return p.A_lo ? launch_split<EPI, true>(p, cg, st) : launch_split<EPI, false>(p, cg, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
