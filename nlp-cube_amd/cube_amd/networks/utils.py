@@ -34,6 +34,7 @@ class MorphoCollate:
         self._add_parsing = add_parsing
         self._rhl_win_size = rhl_win_size
         self._case_cache = {}
+        self._wid_cache = {}
 
     def _char_codes(self, ch):
         """(char id, case id) of one character; case: 1 symbol, 2 upper, 3 lower (utils.py:294-304)."""
@@ -86,7 +87,16 @@ class MorphoCollate:
         si = np.arange(N) - np.repeat(np.cumsum(sent_len) - sent_len, sent_len)
         x_sent = np.zeros((B, L), dtype=np.int64)
         x_sent_masks = np.zeros((B, L), dtype=np.float64)
-        x_sent[sb, si] = np.fromiter((w2i.get(t.lower(), unk) for t in texts), dtype=np.int64, count=N)
+        # word ids (lower-cased look-up, utils.py:284-289) through a cache keyed by the raw token
+        wid = self._wid_cache
+        ids = [wid.get(t) for t in texts]
+        if None in ids:
+            if len(wid) > (1 << 20):
+                wid.clear()
+            for i, t in enumerate(texts):
+                if ids[i] is None:
+                    ids[i] = wid[t] = w2i.get(t.lower(), unk)
+        x_sent[sb, si] = ids
         x_sent_masks[sb, si] = 1
         x_lang_sent = np.fromiter((s.lang_id + 1 for s in batch), dtype=np.int64, count=B)
         x_lang_word = np.repeat(x_lang_sent, sent_len)
