@@ -578,11 +578,7 @@ class Parser(_HipNet):
         ticket for `collect`.  At most two batches may be in flight."""
         self._require_gpu()
         if self._streams is None:
-            # phase 2's kernels are short or small: at the higher stream priority they get in and out
-            # between the chip-filling kernels of phase 1 (measured: +0.5 %, the other way round -1 %)
-            lo_pri, hi_pri = torch.cuda.Stream.priority_range()
-            self._streams = (torch.cuda.Stream(device=self._device, priority=lo_pri),
-                             torch.cuda.Stream(device=self._device, priority=hi_pri))
+            self._streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
             self._slot_free = [None, None]
             self._host_res = [None, None]
             self._n_submitted = 0
