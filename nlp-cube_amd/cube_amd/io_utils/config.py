@@ -91,3 +91,21 @@ class ParserConfig(Config):
         self._valid = True
         if filename is not None:
             self.load(filename)
+
+
+class LemmatizerConfig(Config):
+    """reference: cube/io_utils/config.py:159-178"""
+
+    def __init__(self, filename=None, verbose=False):
+        super().__init__()
+        self.encoder_layers = 2
+        self.encoder_size = 200
+        self.decoder_layers = 2
+        self.decoder_size = 400
+        self.att_proj_size = 100
+        self.upos_emb_size = 100
+        self.lang_emb_size = 100
+        self.char_emb_size = 100
+        self._valid = True
+        if filename is not None:
+            self.load(filename)

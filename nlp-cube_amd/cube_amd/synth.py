@@ -185,6 +185,47 @@ def make_tagger_state_dict(config, enc, ext_word_emb, seed=4321):
     return sd
 
 
+def make_lemmatizer_state_dict(config, enc, seed=2468, out_gain=10.0, rec_gain=3.0, eol_gain=3.0):
+    """Random `state_dict` for `Lemmatizer(config, enc)` (reference: lemmatizer.py:24-69,
+    modules.py:133-143).  A default-initialised random decoder sits in a fixed point and prints
+    one character until the 20 x length failsafe (lemmatizer.py:141); the gains give the decoder
+    LSTM livelier dynamics (rec_gain), logits with clear margins (out_gain) and an end-of-lemma
+    logit that wins every few steps (eol_gain), so that a batch mixes words that stop after a few
+    characters with words that run into the failsafe."""
+    ini = _Init(seed)
+    sd = {}
+    G, C = enc.num_langs, len(enc.char2int)
+    F_, half = 512, 256  # NUM_FILTERS is a constant of the reference (lemmatizer.py:26)
+    le, ue, ce, D = config.lang_emb_size, config.upos_emb_size, config.char_emb_size, config.decoder_size
+    sd["_lang_emb.weight"] = ini.emb(G + 1, le, 0)
+    sd["_upos_emb.weight"] = ini.emb(len(enc.upos2int), ue, 0)
+    sd["_char_emb.weight"] = ini.emb(C + 2, ce, 0)
+    sd["_case_emb.weight"] = ini.emb(4, 16, 0)
+    ini.gated_conv_stack(sd, "_convolutions_char", 5, ce + le + ue + 16, half + le, F_)
+    b = 1.0 / np.sqrt(D)
+    frame = half + ce + le + ue + 16
+    for l in range(config.decoder_layers):
+        nin = frame if l == 0 else D
+        sd["_decoder.weight_ih_l%d" % l] = ini.uniform((4 * D, nin), -b, b) * rec_gain
+        sd["_decoder.weight_hh_l%d" % l] = ini.uniform((4 * D, D), -b, b) * rec_gain
+        sd["_decoder.bias_ih_l%d" % l] = ini.uniform((4 * D,), -b, b)
+        sd["_decoder.bias_hh_l%d" % l] = ini.uniform((4 * D,), -b, b)
+    att_in = (half + le + ue + 16) // 2 * 2 + D
+    sd["_attention.attn.conv.weight"] = ini.xavier((config.att_proj_size, att_in, 5), gain=5.0 / 3.0)
+    ba = 1.0 / np.sqrt(att_in * 5)
+    sd["_attention.attn.conv.bias"] = ini.uniform((config.att_proj_size,), -ba, ba)
+    sd["_attention.v"] = ini.uniform((config.att_proj_size,), 0.0, 1.0)
+    ini.linear(sd, "_output_char.linear_layer", C + 2, D)
+    ini.linear(sd, "_output_case.linear_layer", 4, D)
+    sd["_output_char.linear_layer.weight"] *= out_gain
+    sd["_output_char.linear_layer.weight"][C] *= eol_gain
+    # the stop index C+1 has no entry in `encodings.characters`: a trained model never emits it, and
+    # the reference would raise IndexError if it did (lemmatizer.py:217)
+    sd["_output_char.linear_layer.bias"][C + 1] -= 10.0
+    sd["_start_frame.weight"] = ini.emb(1, frame)
+    return sd
+
+
 # ------------------------------------------------------------------------------------------
 # corpora
 # ------------------------------------------------------------------------------------------

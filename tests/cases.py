@@ -4,7 +4,7 @@ inputs from the same seeds and compare with the stored reference outputs)."""
 import numpy as np
 
 from cube_amd import synth
-from cube_amd.io_utils.config import ParserConfig, TaggerConfig
+from cube_amd.io_utils.config import ParserConfig, TaggerConfig, LemmatizerConfig
 
 # tiny dims: every stage exercised, weights small, reference runs in milliseconds
 TINY = dict(name="tiny", seed=11, ext=(12, 8), dims=dict(char_emb_size=16, char_filter_size=32, char_layers=3,
@@ -49,6 +49,34 @@ def tagger_model(case):
     enc = synth.make_encodings(**case["vocab"])
     sd = synth.make_tagger_state_dict(cfg, enc, list(case["ext"]), seed=case["seed"])
     return cfg, enc, sd
+
+
+LEMMA = dict(name="lemma", seed=2468, ext=(), dims={}, vocab={})
+# smaller embeddings / decoder (NUM_FILTERS = 512 is fixed by the reference, lemmatizer.py:26)
+LEMMA_SMALL = dict(name="lemma_small", seed=97, ext=(), dims=dict(decoder_size=48, att_proj_size=20, upos_emb_size=12,
+                   lang_emb_size=8, char_emb_size=20), vocab=TINY["vocab"])
+
+
+def lemmatizer_model(case):
+    cfg = _cfg(LemmatizerConfig, case["dims"])
+    enc = synth.make_encodings(**case["vocab"])
+    sd = synth.make_lemmatizer_state_dict(cfg, enc, seed=case["seed"])
+    return cfg, enc, sd
+
+
+def lemma_document(enc, key, max_word_len=16):
+    """document for the lemmatizer: words as `document`, plus a UPOS per word (what the parser
+    would have written; some '_' = unknown tag) and no external embeddings."""
+    lens, seed = _DOCS[key]
+    if lens is None:
+        lens = list(np.random.default_rng(seed).integers(1, 25, size=32))
+    doc = synth.make_document(enc, lens, seed=seed, ext_word_emb=(), max_word_len=max_word_len)
+    rng = np.random.default_rng(seed + 5000)
+    tags = [t for t in enc.upos_list if t not in ("<PAD>",)] + ["_"]
+    for s in doc.sentences:
+        for w in s.words:
+            w.upos = tags[int(rng.integers(len(tags)))]
+    return doc
 
 
 def document(case, enc, key):

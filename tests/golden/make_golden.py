@@ -49,6 +49,11 @@ def _import_reference():
     from cube.io_utils.objects import Document, Sentence, Word
     from cube.io_utils.encodings import Encodings
     from cube.io_utils.config import ParserConfig, TaggerConfig
+    from cube.networks.lemmatizer import Lemmatizer
+    from cube.networks.utils import LemmaDataset, Word2TargetCollate
+    from cube.io_utils.config import LemmatizerConfig
+    globals().update(_LEMMA=dict(Lemmatizer=Lemmatizer, LemmaDataset=LemmaDataset, Word2TargetCollate=Word2TargetCollate,
+                                 LemmatizerConfig=LemmatizerConfig))
     return dict(Parser=Parser, Tagger=Tagger, MorphoCollate=MorphoCollate, CLE=ChuLiuEdmondsDecoder,
                 Document=Document, Sentence=Sentence, Word=Word, Encodings=Encodings,
                 ParserConfig=ParserConfig, TaggerConfig=TaggerConfig)
@@ -213,10 +218,54 @@ def g8_tagger_process():
             print("g8", tag, bs)
 
 
+def build_ref_lemmatizer(case):
+    cfg, enc, sd = cases.lemmatizer_model(case)
+    rc = _LEMMA["LemmatizerConfig"]()
+    for k, v in cfg.__dict__.items():
+        if not k.startswith("_"):
+            setattr(rc, k, v)
+    m = _LEMMA["Lemmatizer"](rc, ref_encodings(enc), language_codes=None)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m, cfg, enc
+
+
+def g9_lemmatizer():
+    """Lemmatizer: collate tensors, `forward` (greedy decode) arg-max sequences for every step plus
+    the logits of the first 16 steps, and `process` lemmas at batch sizes 4 and 32."""
+    save = {}
+    for case, tag in ((cases.LEMMA_SMALL, "small"), (cases.LEMMA, "full")):
+        m, cfg, enc = build_ref_lemmatizer(case)
+        col = _LEMMA["Word2TargetCollate"](ref_encodings(enc))
+        for dk, n in (("ragged", 37), ("g6", 128)):
+            doc = ref_document(cases.lemma_document(enc, dk))
+            ds = _LEMMA["LemmaDataset"](doc, for_training=False)
+            batch = col.collate_fn([ds[i] for i in range(min(n, len(ds)))])
+            for k in ("x_char", "x_case", "x_lang", "x_upos"):
+                save["%s/%s/%s" % (tag, dk, k)] = batch[k].numpy()
+            del batch["y_char"], batch["y_case"]
+            with torch.no_grad():
+                yc, yk = m.forward(batch)
+            save["%s/%s/char" % (tag, dk)] = torch.argmax(yc, -1).numpy().astype(np.int16)
+            save["%s/%s/case" % (tag, dk)] = torch.argmax(yk, -1).numpy().astype(np.int8)
+            save["%s/%s/char_logits16" % (tag, dk)] = yc[:, :16].numpy()
+            save["%s/%s/case_logits16" % (tag, dk)] = yk[:, :16].numpy()
+            print("g9", tag, dk, tuple(yc.shape))
+        for bs in (4, 32):
+            doc = ref_document(cases.lemma_document(enc, "g6", max_word_len=6))
+            m.process(doc, col, batch_size=bs, num_workers=0)
+            with open(os.path.join(HERE, "g9_lemmas_%s_bs%d.txt" % (tag, bs)), "w", encoding="utf-8") as f:
+                for s in doc.sentences:
+                    for w in s.words:
+                        f.write(w.word + "\t" + w.lemma + "\n")
+            print("g9 process", tag, bs)
+    np.savez_compressed(os.path.join(HERE, "g9_lemmatizer.npz"), **save)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
     if "g1" in which:
         g1_collate()
     if "g2" in which:
@@ -231,3 +280,5 @@ if __name__ == "__main__":
         g7_tagger()
     if "g8" in which:
         g8_tagger_process()
+    if "g9" in which:
+        g9_lemmatizer()
