@@ -24,6 +24,10 @@
  *                           520-563, 445-518, 404-443)
  *   cube_label_score        Parser._get_labels gather + nn.Bilinear (parser.py:218-233;
  *                           modules.py:536-547)
+ *   cube_lemma_attend       Lemmatizer greedy step: torch.argmax + _char_emb feedback
+ *                           (cube/networks/lemmatizer.py:160-167), Attention.forward
+ *                           (modules.py:145-169), context bmm (lemmatizer.py:144-145)
+ *   cube_lstm_cell          one time step of the decoder nn.LSTM cell (lemmatizer.py:152-154)
  */
 #ifndef CUBE_HIP_H
 #define CUBE_HIP_H
@@ -177,6 +181,39 @@ int cube_label_score(const void* hl, const void* hl_lo, int ld_hl, int col_x2, i
                      const void* wl, const void* wl_lo, const float* bias,
                      int n_labels, const int32_t* heads, const int32_t* lens, int B, int L,
                      float* logits, int32_t* labels, void* stream);
+
+/* ---- lemmatizer decoder ---------------------------------------------------
+ * One greedy decoding step for B words between the GEMMs of the step.  q f32 [B, ld_q] is the output
+ * of the per-step "query" GEMM: columns [t*ld_tap, t*ld_tap + P) hold W_att[:, query channels, tap t]
+ * . query (the query is the top layer's CELL state, lemmatizer.py:144), columns [col_char, +n_char)
+ * and [col_case, +n_case) the character / case logits of the PREVIOUS decoder step.
+ *   step > 0: out_char/out_case[b, step-1] = first arg-max of those logits; done[b] / *n_done are
+ *             updated when the character is `eol`; x[b, col_emb..+E) = char_emb[arg-max].
+ *   step = 0: x[b, col_emb..+E) = 0 (no previous character, lemmatizer.py:147-149).
+ *   attend != 0: energy[t] = v . tanh(e_enc[b*S+t, :] + sum over taps t+k-taps/2 inside [0, S) of
+ *             q[b, k*ld_tap + :]) (Conv1d(k=taps) over [query | encoder_output] with the query
+ *             constant along the word, e_enc = the encoder part + bias, computed once per batch);
+ *             att = softmax over all S positions; x[b, col_ctx..+C) = sum_t att[t] * enc[b*S+t, 0..C).
+ * enc, char_emb, x: bf16 hi (+ lo) planes.  S <= 256, P <= 128, C <= 512, C % 8 == 0.              */
+typedef struct cube_lemma_attend_args {
+  const float* q; int ld_q; int taps; int P; int ld_tap;
+  int col_char; int n_char; int col_case; int n_case;
+  const float* v; const float* e_enc; int ld_e;
+  const void* enc; const void* enc_lo; int ld_enc; int C;
+  int B; int S;
+  const void* char_emb; const void* char_emb_lo; int ld_emb; int E;
+  void* x; void* x_lo; int ld_x; int col_ctx; int col_emb;
+  int step; int attend;
+  int32_t* out_char; int32_t* out_case; int ld_out;
+  int eol; int32_t* done; int32_t* n_done;
+} cube_lemma_attend_args;
+int cube_lemma_attend(const cube_lemma_attend_args* args, void* stream);
+
+/* LSTM cell: gates f32 [B, ld_g] = W_ih x + W_hh h + b, columns [i | f | g | o] of H each (PyTorch
+ * order); c f32 [B, H] updated in place; h = o * tanh(c) -> bf16 hi (+ lo) at h[b, col_h..+H) (row
+ * stride ld_h); optionally c as bf16 hi (+ lo) at c16[b, col_c..+H) (same stride).               */
+int cube_lstm_cell(const float* gates, int ld_g, int H, float* c, int B, void* h, void* h_lo, int ld_h, int col_h,
+                   void* c16, void* c16_lo, int col_c, void* stream);
 
 #ifdef __cplusplus
 }

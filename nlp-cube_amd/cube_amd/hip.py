@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 6  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 7  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -37,6 +37,22 @@ class GemmArgs(ctypes.Structure):
         ("out2", c_void_p), ("out2_lo", c_void_p), ("ldo2", c_int), ("col2", c_int),
         ("bias_tab", c_void_p), ("row_group", c_void_p), ("n_groups", c_int),
         ("groups", ctypes.POINTER(ConvGroups)),
+    ]
+
+
+class LemmaAttendArgs(ctypes.Structure):
+    """cube_lemma_attend_args (include/cube_hip.h)."""
+    _fields_ = [
+        ("q", c_void_p), ("ld_q", c_int), ("taps", c_int), ("P", c_int), ("ld_tap", c_int),
+        ("col_char", c_int), ("n_char", c_int), ("col_case", c_int), ("n_case", c_int),
+        ("v", c_void_p), ("e_enc", c_void_p), ("ld_e", c_int),
+        ("enc", c_void_p), ("enc_lo", c_void_p), ("ld_enc", c_int), ("C", c_int),
+        ("B", c_int), ("S", c_int),
+        ("char_emb", c_void_p), ("char_emb_lo", c_void_p), ("ld_emb", c_int), ("E", c_int),
+        ("x", c_void_p), ("x_lo", c_void_p), ("ld_x", c_int), ("col_ctx", c_int), ("col_emb", c_int),
+        ("step", c_int), ("attend", c_int),
+        ("out_char", c_void_p), ("out_case", c_void_p), ("ld_out", c_int),
+        ("eol", c_int), ("done", c_void_p), ("n_done", c_void_p),
     ]
 
 
@@ -85,6 +101,9 @@ SIGNATURES = {
     "cube_mst_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cube_label_score": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cube_lemma_attend": (c_int, [ctypes.POINTER(LemmaAttendArgs), c_void_p]),
+    "cube_lstm_cell": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                               c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,314 @@
+"""MI355X-native character-level lemmatizer (inference), SURVEY.md §8f row 2.
+
+Host-side mirror of the reference `Lemmatizer` (cube/networks/lemmatizer.py:20-231) with its
+`LemmaDataset` / `Word2TargetCollate` (cube/networks/utils.py:99-122, 153-223): same constructor,
+`load`, `forward(X)` and `process(doc, collate, batch_size, num_workers)` and the same results,
+with every tensor operation in gfx950 kernels behind the C ABI of include/cube_hip.h.
+
+Per batch of words: the gated char CNN encoder runs once (5 x cube_gemm_bf16 with the gate
+epilogue, language embedding folded into per-(language, tap mask) bias tables), then the attention
+Conv1d is split: its encoder half is one implicit-conv GEMM per batch, its query half (the query is
+constant along the word) is part of the per-step "query" GEMM together with the two output heads.
+A greedy step is 3 GEMMs + 3 row kernels, all asynchronous; the host looks at the device's
+finished-word counter every `CHECK_EVERY` steps instead of every step (lemmatizer.py:139,161-163).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from cube_amd import hip
+from cube_amd.networks import packing
+from cube_amd.networks.parser import _Buffers
+
+
+class LemmaDataset:
+    """reference: utils.py:99-122.  Inference keeps one example per word (no de-duplication) and
+    skips words longer than 25 characters (:109-110)."""
+
+    def __init__(self, document, for_training=True):
+        self._examples = []
+        lookup = {}
+        for sent in document.sentences:
+            for w in sent.words:
+                if len(w.word) > 25:
+                    continue
+                key = (w.word, sent.lang_id, w.upos)
+                if key not in lookup or for_training is False:
+                    lookup[key] = 1
+                    self._examples.append({"word": w.word, "upos": w.upos, "lang_id": sent.lang_id, "target": w.lemma})
+
+    def __len__(self):
+        return len(self._examples)
+
+    def __getitem__(self, item):
+        return self._examples[item]
+
+
+class Word2TargetCollate:
+    """reference: utils.py:153-223 — same keys, dtypes and values (pinned by tests/golden/g9)."""
+
+    def __init__(self, encodings):
+        self._encodings = encodings
+        self._start_index = len(encodings.char2int)
+        self._stop_index = len(encodings.char2int) + 1
+        self._eol = len(encodings.char2int)
+        self._codes = {}
+
+    def _code(self, ch):
+        hit = self._codes.get(ch)
+        if hit is None:
+            lo = ch.lower()
+            case = 1 if lo == ch.upper() else (2 if lo != ch else 3)
+            hit = self._codes[ch] = (self._encodings.char2int.get(lo, self._encodings.char2int["<UNK>"]), case)
+        return hit
+
+    def _fill(self, texts, width, first, last):
+        n = len(texts)
+        chars = np.zeros((n, width), dtype=np.int64)
+        case = np.zeros((n, width), dtype=np.int64)
+        for i, t in enumerate(texts):
+            if first is not None:
+                chars[i, 0] = first
+            p = 0 if first is None else 1
+            for ch in t:
+                chars[i, p], case[i, p] = self._code(ch)
+                p += 1
+            chars[i, p] = last
+        return chars, case
+
+    def collate_fn(self, batch, targets=True):
+        enc = self._encodings
+        words = [e["word"] for e in batch]
+        x_char, x_case = self._fill(words, max(len(w) for w in words) + 2, self._start_index, self._stop_index)
+        unk = enc.upos2int["<UNK>"]
+        out = {
+            "x_char": torch.from_numpy(x_char), "x_case": torch.from_numpy(x_case),
+            "x_lang": torch.tensor([e["lang_id"] + 1 for e in batch], dtype=torch.long),
+            "x_upos": torch.tensor([enc.upos2int.get(e.get("upos", ""), unk) for e in batch], dtype=torch.long),
+        }
+        if targets:
+            tg = [e["target"] for e in batch]
+            y_char, y_case = self._fill(tg, max(len(t) for t in tg) + 1, None, self._eol)
+            out["y_char"], out["y_case"] = torch.from_numpy(y_char), torch.from_numpy(y_case)
+        return out
+
+
+class Lemmatizer:
+    CHECK_EVERY = 8  # greedy steps between two looks at the finished-word counter
+
+    def __init__(self, config, encodings, language_codes=None):
+        if config.decoder_layers != 2:
+            raise ValueError("the HIP lemmatizer implements the reference's 2-layer decoder (LemmatizerConfig default)")
+        self._config = config
+        self._encodings = encodings
+        self._num_languages = encodings.num_langs
+        self._language_codes = language_codes
+        self._eol = len(encodings.char2int)
+        self._device = torch.device("cpu")
+        self._pk_cpu = self._pk = self._lay = self._buf = None
+        self.training = False
+        self.precision = "bf16x3"
+
+    # ---- reference-compatible module surface ----------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._pk_cpu, self._lay = packing.pack_lemmatizer(state_dict, self._config, len(self._encodings.char2int))
+        self._pk = None
+        if self._device.type == "cuda":
+            self.to(self._device)
+
+    def load(self, model_path, device="cpu"):
+        """reference: lemmatizer.py:176-178 (Lightning checkpoint, only ['state_dict'] is read)."""
+        self.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True)["state_dict"])
+        self.to(device)
+
+    def to(self, device):
+        device = torch.device(device)
+        self._device = device
+        if device.type != "cuda":
+            return self  # the reference defaults to 'cpu'; this implementation has no CPU path
+        hip.load()
+        if self._pk_cpu is not None:
+            if self.precision not in ("bf16x3", "bf16"):
+                raise ValueError("precision must be 'bf16x3' or 'bf16'")
+            self._split = self.precision == "bf16x3"
+            self._pk = packing.to_device(self._pk_cpu, device, with_lo=self._split)
+            self._buf = _Buffers(device, self._split)
+        return self
+
+    def _require_gpu(self):
+        if self._pk is None or self._device.type != "cuda":
+            raise hip.CubeHipError("cube_amd Lemmatizer runs only on an MI355X: load weights and call .to('cuda:N') "
+                                   "(there is no CPU fallback)")
+
+    # ---- device pipeline -------------------------------------------------------------------
+    def _gather(self, dst, ld, col0, width, table, idx, n):
+        lo = dst.lo is not None and table.lo is not None
+        hip.check(hip.load().cube_gather_rows(dst.hi.data_ptr(), hip.ptr(dst.lo) if lo else None, ld, col0, width,
+                                              table.hi.data_ptr(), hip.ptr(table.lo) if lo else None, table.hi.shape[1],
+                                              hip.ptr(idx), None, n, hip.stream_handle()), "cube_gather_rows")
+
+    def _encode(self, X):
+        """lemmatizer.py:89-124 + the encoder half of the attention Conv1d (modules.py:141,156).
+        -> dict(B, S, enc Pair [B*S, enc_w], e_enc f32 [B*S, N])"""
+        pk, lay, buf, dev, st = self._pk, self._lay, self._buf, self._device, hip.stream_handle()
+        x_char = X["x_char"].cpu().numpy()
+        B, S = x_char.shape
+        M = B * S
+        parts = [x_char.reshape(-1), X["x_case"].cpu().numpy().reshape(-1), np.repeat(X["x_upos"].cpu().numpy(), S),
+                 np.repeat(X["x_lang"].cpu().numpy(), S)]
+        ints = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(dev, non_blocking=True)
+        char_i, case_i, upos_i, lang_i = (ints[k * M:(k + 1) * M] for k in range(4))
+        self._live = [ints]  # per-batch device inputs: referenced until the next batch replaces them
+        xe0 = buf.get("xe0", M, lay.xe0_w)
+        self._gather(xe0, lay.xe0_w, 0, packing.p8(lay.ce), pk["char_emb"], char_i, M)
+        self._gather(xe0, lay.xe0_w, lay.xe0_case, lay.case, pk["case_emb"], case_i, M)
+        self._gather(xe0, lay.xe0_w, lay.xe0_upos, packing.p8(lay.ue), pk["upos_emb"], upos_i, M)
+        enc = buf.get("enc", M, lay.enc_w)
+        self._gather(enc, lay.enc_w, lay.enc_case, lay.case, pk["case_emb"], case_i, M)
+        self._gather(enc, lay.enc_w, lay.enc_upos, packing.p8(lay.ue), pk["upos_emb"], upos_i, M)
+        self._gather(enc, lay.enc_w, lay.enc_lang, packing.p8(lay.le), pk["lang_emb"], lang_i, M)
+        ga, gb = buf.get("ga", M, lay.half), buf.get("gb", M, lay.half)
+        res = buf.get("res", M, lay.half, torch.float32)
+        src, src_ld = xe0, lay.xe0_w
+        n = len(pk["convs"])
+        for l, cv in enumerate(pk["convs"]):
+            last = l == n - 1
+            dst = None if last else (ga if l % 2 == 0 else gb)
+            hip.gemm(src, src_ld, M, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.half, col0=0,
+                     taps=cv["taps"], seq_len=S, n_valid=cv["half"], res=res, ld_res=lay.half, res_mode=0 if l == 0 else 1,
+                     out1=enc if last else None, ldo1=lay.enc_w, col1=0, bias_tab=cv["bias_tab"], row_group=lang_i, stream=st)
+            src, src_ld = dst, lay.half
+        ae = pk["att_enc"]
+        e_enc = buf.get("e_enc", M, ae["N"], torch.float32)
+        hip.gemm(enc, lay.enc_w, M, ae["Kc"], ae["W"], ae["N"], ae["bias"], hip.EPI_F32, out0=e_enc, ldo0=ae["N"],
+                 n_valid=ae["N"], taps=ae["taps"], seq_len=S, stream=st)
+        return dict(B=B, S=S, enc=enc, e_enc=e_enc, ld_e=ae["N"], _ints=ints)
+
+    def _decode(self, ed, max_steps=None, keep_logits=False):
+        """Greedy decoding (lemmatizer.py:126-169).  -> (out_char i32 [B, n], out_case i32 [B, n], n, logits)
+        with n = the number of steps the reference would have run."""
+        lib, pk, lay, buf, dev, st = hip.load(), self._pk, self._lay, self._buf, self._device, hip.stream_handle()
+        B, S = ed["B"], ed["S"]
+        limit = S * 20 if max_steps is None else max_steps
+        D, ld_x = lay.D, lay.xd_w
+        xd = buf.get("xd", B, ld_x)
+        xd.hi[:B * ld_x].zero_()
+        if xd.lo is not None:
+            xd.lo[:B * ld_x].zero_()
+        cs = buf.get("cells", 2 * B, D, torch.float32)
+        cs[:2 * B * D].zero_()
+        c0, c1 = cs[:B * D], cs[B * D:2 * B * D]
+        l0, l1, qq = pk["lstm0"], pk["lstm1"], pk["query"]
+        gates = buf.get("gates", B, l0["N"], torch.float32)
+        q = buf.get("q", B, qq["N"], torch.float32)
+        out = torch.zeros((2, B, max(limit, 1)), dtype=torch.int32, device=dev)
+        flags = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        logits = torch.zeros((limit, B, lay.n_char + lay.n_case), dtype=torch.float32, device=dev) if keep_logits else None
+        self._live += [out, flags, logits]
+        lo = hip.ptr
+
+        def lstm():
+            hip.gemm(xd, ld_x, B, l0["K"], l0["W"], l0["N"], l0["bias"], hip.EPI_F32, out0=gates, ldo0=l0["N"],
+                     n_valid=l0["N"], stream=st)
+            hip.check(lib.cube_lstm_cell(gates.data_ptr(), l0["N"], D, c0.data_ptr(), B, xd.hi.data_ptr(), lo(xd.lo), ld_x,
+                                         lay.xd_h0, None, None, 0, st), "cube_lstm_cell")
+            hip.gemm(xd, ld_x, B, l1["K"], l1["W"], l1["N"], l1["bias"], hip.EPI_F32, out0=gates, ldo0=l1["N"],
+                     n_valid=l1["N"], a_col=lay.xd_h0, stream=st)
+            hip.check(lib.cube_lstm_cell(gates.data_ptr(), l1["N"], D, c1.data_ptr(), B, xd.hi.data_ptr(), lo(xd.lo), ld_x,
+                                         lay.xd_h1, xd.hi.data_ptr(), lo(xd.lo), lay.xd_c1, st), "cube_lstm_cell")
+
+        a = hip.LemmaAttendArgs()
+        a.q, a.ld_q, a.taps, a.P, a.ld_tap = q.data_ptr(), qq["N"], pk["att_enc"]["taps"], lay.P, lay.ld_tap
+        a.col_char, a.n_char, a.col_case, a.n_case = lay.q_char, lay.n_char, lay.q_case, lay.n_case
+        a.v, a.e_enc, a.ld_e = pk["att_v"].data_ptr(), ed["e_enc"].data_ptr(), ed["ld_e"]
+        a.enc, a.enc_lo, a.ld_enc, a.C = ed["enc"].hi.data_ptr(), lo(ed["enc"].lo), lay.enc_w, lay.enc_c
+        a.B, a.S = B, S
+        a.char_emb, a.char_emb_lo = pk["char_emb"].hi.data_ptr(), lo(pk["char_emb"].lo)
+        a.ld_emb, a.E = pk["char_emb"].hi.shape[1], packing.p8(lay.ce)
+        a.x, a.x_lo, a.ld_x, a.col_ctx, a.col_emb = xd.hi.data_ptr(), lo(xd.lo), ld_x, 0, lay.xd_emb
+        a.out_char, a.out_case, a.ld_out = out[0].data_ptr(), out[1].data_ptr(), out.shape[2]
+        a.eol, a.done, a.n_done = self._eol, flags.data_ptr(), flags[B:].data_ptr()
+
+        # start frame through the decoder with a zero state (lemmatizer.py:128-131)
+        self._gather(xd, ld_x, 0, lay.xd_h0, pk["start"], None, B)
+        lstm()
+        steps = 0
+        for s in range(limit + 1):
+            hip.gemm(xd, ld_x, B, qq["K"], qq["W"], qq["N"], qq["bias"], hip.EPI_F32, out0=q, ldo0=qq["N"], n_valid=qq["N"],
+                     a_col=lay.xd_h1, stream=st)
+            if keep_logits and s > 0:
+                logits[s - 1].copy_(q[:B * qq["N"]].view(B, qq["N"])[:, lay.q_char:lay.q_char + lay.n_char + lay.n_case])
+            a.step, a.attend = s, int(s < limit)
+            hip.check(lib.cube_lemma_attend(ctypes.byref(a), st), "cube_lemma_attend")
+            steps = s
+            if s == limit:
+                break
+            if s > 0 and s % self.CHECK_EVERY == 0 and int(flags[B].item()) == B:
+                break
+            lstm()
+        res = out[:, :, :max(steps, 1)].cpu().numpy()
+        oc, ok = res[0][:, :steps], res[1][:, :steps]
+        # the reference stops right after the step at which the last word emitted EOL (lemmatizer.py:139)
+        n = steps
+        if steps > 0:
+            is_eol = oc == self._eol
+            if is_eol.any(axis=1).all():
+                n = int(is_eol.argmax(axis=1).max()) + 1
+        return oc[:, :n], ok[:, :n], n, (None if logits is None else logits[:n])
+
+    def forward(self, X):
+        """-> (char logits [B, n, C+2], case logits [B, n, 4]) of the greedy decode, as the reference's
+        inference branch returns them (lemmatizer.py:171).  Teacher forcing ('y_char' in X) is training-only
+        and not implemented."""
+        self._require_gpu()
+        if "y_char" in X:
+            raise NotImplementedError("teacher-forced forward is a training path; delete y_char / y_case as process() does")
+        oc, ok, n, logits = self._decode(self._encode(X), keep_logits=True)
+        logits = logits.permute(1, 0, 2)
+        return logits[:, :, :self._lay.n_char], logits[:, :, self._lay.n_char:]
+
+    def decode_batch(self, X):
+        """-> (chars int32 [B, n], cases int32 [B, n]) arg-max sequences (NumPy), no logits kept."""
+        self._require_gpu()
+        oc, ok, _, _ = self._decode(self._encode(X))
+        return oc, ok
+
+    def _strings(self, oc, ok):
+        chars = self._encodings.characters
+        out = []
+        for row_c, row_k in zip(oc.tolist(), ok.tolist()):
+            s = []
+            for c, k in zip(row_c, row_k):
+                if c == self._eol:
+                    break
+                ch = chars[c]  # IndexError for the stop index, like the reference (lemmatizer.py:217)
+                if k == 2:
+                    ch = ch.upper()
+                elif k == 3:
+                    ch = ch.lower()
+                s.append(ch)
+            out.append("".join(s))
+        return out
+
+    def process(self, doc, collate, batch_size=4, num_workers=4):
+        """reference: lemmatizer.py:185-231.  `num_workers` is accepted and ignored."""
+        self._require_gpu()
+        dataset = LemmaDataset(doc, for_training=False)
+        all_lemmas = []
+        for s in range(0, len(dataset), batch_size):
+            items = [dataset[i] for i in range(s, min(s + batch_size, len(dataset)))]
+            batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
+            batch.pop("y_char", None)
+            batch.pop("y_case", None)
+            all_lemmas.extend(self._strings(*self.decode_batch(batch)))
+        i = 0
+        for sent in doc.sentences:
+            for w in sent.words:
+                w.lemma = all_lemmas[i]  # IndexError when a word was skipped (> 25 characters), as in the reference
+                i += 1
+        return doc

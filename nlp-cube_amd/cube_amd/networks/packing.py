@@ -360,3 +360,138 @@ def to_device(obj, device, with_lo=True):
     if isinstance(obj, list):
         return [to_device(v, device, with_lo) for v in obj]
     return obj
+
+
+# ------------------------------------------------------------------------------------------
+# lemmatizer (reference: cube/networks/lemmatizer.py:24-69)
+# ------------------------------------------------------------------------------------------
+def p8(x):
+    return (x + 7) // 8 * 8
+
+
+def _dense(rows, cols):
+    return torch.zeros((rows, cols), dtype=torch.float32)
+
+
+def pack_conv_plain(w, b, in_perm):
+    """Conv1d weight [F, Cin, taps] -> W bf16 [pad128(F), taps*Kc] in the K order of cube_gemm_bf16
+    (32-channel chunk outer, tap inner), bias f32 [pad128(F)].  in_perm: buffer column -> input channel."""
+    w = w.float()
+    F_, cin, taps = w.shape
+    in_perm = np.asarray(in_perm)
+    Kc, N = p32(len(in_perm)), p128(F_)
+    vk = np.where(in_perm >= 0)[0]
+    W = torch.zeros((N, taps, Kc), dtype=torch.float32)
+    W[:F_, :, torch.from_numpy(vk)] = w[:, torch.from_numpy(in_perm[vk]), :].permute(0, 2, 1)
+    W = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)
+    bias = torch.zeros(N, dtype=torch.float32)
+    bias[:F_] = b.float()
+    return dict(W=_bf16(W), bias=bias, Kc=Kc, N=N, taps=taps)
+
+
+class LemmaLayout:
+    """Column layouts of the lemmatizer's activation buffers (bf16 elements; segments padded to 8
+    so that every row copy is 16-byte aligned).
+      XE0 [char | case | upos]                      input of the first gated conv (lang: bias table)
+      ENC [x+res 256 | case | upos | lang]          encoder_output (lemmatizer.py:124), C = enc_c
+      XD  [ctx (ENC layout) | prev char | h0 | h1 | c1]   decoder state row of a word"""
+
+    def __init__(self, cfg, n_chars):
+        self.ce, self.ue, self.le, self.D, self.P = (cfg.char_emb_size, cfg.upos_emb_size, cfg.lang_emb_size,
+                                                     cfg.decoder_size, cfg.att_proj_size)
+        self.half, self.case = 256, 16
+        self.n_char, self.n_case = n_chars + 2, 4
+        self.xe0_case, self.xe0_upos = p8(self.ce), p8(self.ce) + self.case
+        self.xe0_w = p32(self.xe0_upos + p8(self.ue))
+        self.enc_case, self.enc_upos = self.half, self.half + self.case
+        self.enc_lang = self.enc_upos + p8(self.ue)
+        self.enc_c = self.enc_lang + p8(self.le)
+        self.enc_w = p32(self.enc_c)
+        self.xd_emb = self.enc_w
+        self.xd_h0 = self.xd_emb + p32(self.ce)
+        self.xd_h1 = self.xd_h0 + p32(self.D)
+        self.xd_c1 = self.xd_h1 + p32(self.D)
+        self.xd_w = self.xd_c1 + p32(self.D)
+        self.ld_tap = p8(self.P)
+        self.q_char = 5 * self.ld_tap
+        self.q_case = self.q_char + self.n_char
+
+    def xe0_perm(self):
+        """XE0 column -> input channel of the first conv ([char, case, upos, lang], lemmatizer.py:92-98,113)."""
+        perm = -np.ones(self.xe0_w, dtype=np.int64)
+        perm[:self.ce] = np.arange(self.ce)
+        perm[self.xe0_case:self.xe0_case + self.case] = self.ce + np.arange(self.case)
+        perm[self.xe0_upos:self.xe0_upos + self.ue] = self.ce + self.case + np.arange(self.ue)
+        return perm
+
+    def enc_perm(self):
+        """ENC column -> channel of encoder_output ([x, case, upos, lang], lemmatizer.py:124)."""
+        perm = -np.ones(self.enc_w, dtype=np.int64)
+        perm[:self.half + self.case] = np.arange(self.half + self.case)
+        perm[self.enc_upos:self.enc_upos + self.ue] = self.half + self.case + np.arange(self.ue)
+        perm[self.enc_lang:self.enc_lang + self.le] = self.half + self.case + self.ue + np.arange(self.le)
+        return perm
+
+
+def pack_lemmatizer(sd, cfg, n_chars):
+    lay = LemmaLayout(cfg, n_chars)
+    ce, ue, le, D, P, half = lay.ce, lay.ue, lay.le, lay.D, lay.P, lay.half
+    pk = {}
+    pk["char_emb"] = pack_table(sd["_char_emb.weight"], p8(ce))
+    pk["case_emb"] = pack_table(sd["_case_emb.weight"])
+    pk["upos_emb"] = pack_table(sd["_upos_emb.weight"], p8(ue))
+    pk["lang_emb"] = pack_table(sd["_lang_emb.weight"], p8(le))
+    lang = sd["_lang_emb.weight"].float()
+    pk["convs"] = []
+    n_layers = sum(1 for k in sd if k.startswith("_convolutions_char.") and k.endswith(".0.conv.weight"))
+    for l in range(n_layers):
+        if l == 0:
+            cv = pack_gated_conv(sd, "_convolutions_char.0", lay.xe0_perm(), bcast=(ce + lay.case + ue + np.arange(le), lang))
+        else:  # x = dropout(tmp) + skip = 2 tmp (lemmatizer.py:110-111,121): the factor goes into the weights
+            cv = pack_gated_conv(sd, "_convolutions_char.%d" % l, np.arange(half), double_first=half,
+                                 bcast=(half + np.arange(le), lang))
+        pk["convs"].append(cv)
+    # attention Conv1d over [query (D) | encoder_output]: the encoder part once per batch ...
+    wa, ba = sd["_attention.attn.conv.weight"].float(), sd["_attention.attn.conv.bias"].float()
+    enc_perm = lay.enc_perm()
+    pk["att_enc"] = pack_conv_plain(wa, ba, np.where(enc_perm >= 0, enc_perm + D, -1))
+    pk["att_v"] = sd["_attention.v"].float().contiguous()
+    # ... the query part per step, in one GEMM with the output heads: A = [h1 | c1]
+    KD = p32(D)
+    nq = p128(lay.q_case + lay.n_case)
+    Wq, bq = _dense(nq, 2 * KD), torch.zeros(nq, dtype=torch.float32)
+    for k in range(wa.shape[2]):
+        Wq[k * lay.ld_tap:k * lay.ld_tap + P, KD:KD + D] = wa[:, :D, k]          # query = cell state c1
+    Wq[lay.q_char:lay.q_char + lay.n_char, :D] = sd["_output_char.linear_layer.weight"].float()
+    bq[lay.q_char:lay.q_char + lay.n_char] = sd["_output_char.linear_layer.bias"].float()
+    Wq[lay.q_case:lay.q_case + lay.n_case, :D] = sd["_output_case.linear_layer.weight"].float()
+    bq[lay.q_case:lay.q_case + lay.n_case] = sd["_output_case.linear_layer.bias"].float()
+    pk["query"] = dict(W=_bf16(Wq), bias=bq, K=2 * KD, N=nq)
+    # decoder LSTM: layer 0 reads [ctx | prev char | h0], layer 1 reads [h0 | h1]
+    ng = p128(4 * D)
+    vk = torch.from_numpy(np.where(enc_perm >= 0)[0])
+    src = torch.from_numpy(enc_perm[enc_perm >= 0])
+    w_ih, w_hh = sd["_decoder.weight_ih_l0"].float(), sd["_decoder.weight_hh_l0"].float()
+    W0 = _dense(ng, lay.xd_h1)
+    tmp = torch.zeros((4 * D, lay.enc_w), dtype=torch.float32)
+    tmp[:, vk] = w_ih[:, src]
+    W0[:4 * D, :lay.enc_w] = tmp
+    n_ctx = half + lay.case + ue + le
+    W0[:4 * D, lay.xd_emb:lay.xd_emb + ce] = w_ih[:, n_ctx:n_ctx + ce]
+    W0[:4 * D, lay.xd_h0:lay.xd_h0 + D] = w_hh
+    b0 = torch.zeros(ng, dtype=torch.float32)
+    b0[:4 * D] = sd["_decoder.bias_ih_l0"].float() + sd["_decoder.bias_hh_l0"].float()
+    pk["lstm0"] = dict(W=_bf16(W0), bias=b0, K=lay.xd_h1, N=ng)
+    W1 = _dense(ng, 2 * KD)
+    W1[:4 * D, :D] = sd["_decoder.weight_ih_l1"].float()
+    W1[:4 * D, KD:KD + D] = sd["_decoder.weight_hh_l1"].float()
+    b1 = torch.zeros(ng, dtype=torch.float32)
+    b1[:4 * D] = sd["_decoder.bias_ih_l1"].float() + sd["_decoder.bias_hh_l1"].float()
+    pk["lstm1"] = dict(W=_bf16(W1), bias=b1, K=2 * KD, N=ng)
+    # start frame (lemmatizer.py:128-131) laid out as the [ctx | prev char] part of a decoder row
+    sf = sd["_start_frame.weight"].float()[0]
+    row = torch.zeros((1, lay.xd_h0), dtype=torch.float32)
+    row[0, vk] = sf[src]
+    row[0, lay.xd_emb:lay.xd_emb + ce] = sf[n_ctx:n_ctx + ce]
+    pk["start"] = _bf16(row)
+    return pk, lay

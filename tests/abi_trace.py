@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 6
+        return 7
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -246,6 +246,66 @@ class TraceLib:
         self._need("label logits", logits, 4 * B * L * n_labels, 4)
         self._need("label labels", labels, 4 * B * L, 4)
         return 0
+
+
+    def cube_lemma_attend(self, ref, stream):
+        a = ref._obj
+        self.calls.append(("lemma_attend", a.B, a.S, a.step, a.attend))
+        B, S = a.B, a.S
+        assert a.step >= 0 and a.col_emb >= 0 and a.col_emb + a.E <= a.ld_x
+        self._need("attend q", a.q, 4 * B * a.ld_q, 4)
+        for nm, p in (("x", a.x), ("x_lo", a.x_lo)):
+            self._need("attend " + nm, p, 2 * B * a.ld_x, 16)
+        if a.step > 0:
+            assert a.step <= a.ld_out and a.col_char + a.n_char <= a.ld_q and a.col_case + a.n_case <= a.ld_q
+            assert a.E <= a.ld_emb
+            for nm, p in (("out_char", a.out_char), ("out_case", a.out_case)):
+                self._need("attend " + nm, p, 4 * ((B - 1) * a.ld_out + a.step), 4)
+            self._need("attend done", a.done, 4 * B, 4)
+            self._need("attend n_done", a.n_done, 4, 4)
+            for nm, p in (("char_emb", a.char_emb), ("char_emb_lo", a.char_emb_lo)):
+                self._need("attend " + nm, p, 2 * ((a.n_char - 1) * a.ld_emb + a.E), 2)   # any arg-max < n_char
+        if a.attend:
+            assert 0 < S <= 256 and 0 < a.P <= 128 and a.taps in (1, 3, 5) and a.P <= a.ld_tap and a.taps * a.ld_tap <= a.ld_q
+            assert a.P <= a.ld_e and 0 < a.C <= 512 and a.C % 8 == 0 and a.ld_enc % 8 == 0 and a.C <= a.ld_enc
+            assert a.col_ctx % 8 == 0 and a.ld_x % 8 == 0 and a.col_ctx + a.C <= a.ld_x
+            self._need("attend v", a.v, 4 * a.P, 4)
+            self._need("attend e_enc", a.e_enc, 4 * ((B * S - 1) * a.ld_e + a.P), 4)
+            for nm, p in (("enc", a.enc), ("enc_lo", a.enc_lo)):
+                self._need("attend " + nm, p, 2 * ((B * S - 1) * a.ld_enc + a.C), 16)
+        return 0
+
+    def cube_lstm_cell(self, gates, ld_g, H, c, B, h, h_lo, ld_h, col_h, c16, c16_lo, col_c, stream):
+        self.calls.append(("lstm_cell", B, H))
+        assert ld_g >= 4 * H and col_h >= 0 and col_h + H <= ld_h
+        self._need("cell gates", gates, 4 * ((B - 1) * ld_g + 4 * H), 4)
+        self._need("cell c", c, 4 * B * H, 4)
+        for nm, p in (("h", h), ("h_lo", h_lo)):
+            self._need("cell " + nm, p, 2 * ((B - 1) * ld_h + col_h + H), 2)
+        if c16:
+            assert col_c >= 0 and col_c + H <= ld_h
+            for nm, p in (("c16", c16), ("c16_lo", c16_lo)):
+                self._need("cell " + nm, p, 2 * ((B - 1) * ld_h + col_c + H), 2)
+        return 0
+
+
+def dry_lemmatizer(cfg, enc, sd, precision, monkeypatch):
+    """A Lemmatizer whose device is the host and whose library is a TraceLib."""
+    from cube_amd.networks import packing
+    from cube_amd.networks import parser as parser_mod
+    from cube_amd.networks.lemmatizer import Lemmatizer
+    m = Lemmatizer(cfg, enc)
+    m.precision = precision
+    m.load_state_dict(sd)
+    m._device = torch.device("cpu")
+    m._split = precision == "bf16x3"
+    m._pk = packing.to_device(m._pk_cpu, "cpu", with_lo=m._split)
+    m._buf = parser_mod._Buffers("cpu", m._split)
+    lib = TraceLib([lambda: m._pk, lambda: m._buf._b, lambda: getattr(m, "_live", None)])
+    monkeypatch.setattr(hip, "load", lambda: lib)
+    monkeypatch.setattr(hip, "stream_handle", lambda: 0)
+    monkeypatch.setattr(m, "_require_gpu", lambda: None)
+    return m, lib
 
 
 def dry_net(cls, case_cfg, enc, sd, ext, precision, monkeypatch):

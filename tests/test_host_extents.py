@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from tests import cases
+from tests import abi_trace
 from tests.abi_trace import dry_parser, ExtentError
 
 
@@ -92,3 +93,20 @@ def test_tagger_extents(monkeypatch, case):
         assert tuple(r["packed"].shape) == (3, B, L)
     names = [c[0] for c in lib.calls]
     assert "bilstm" not in names and "mst" not in names
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", [cases.LEMMA_SMALL, cases.LEMMA], ids=["small", "full"])
+def test_lemmatizer_host_extents(case, precision, monkeypatch):
+    """Every pointer of the lemmatizer's encoder + a few greedy steps covers what its kernel touches."""
+    from cube_amd.networks.lemmatizer import LemmaDataset, Word2TargetCollate
+    cfg, enc, sd = cases.lemmatizer_model(case)
+    m, lib = abi_trace.dry_lemmatizer(cfg, enc, sd, precision, monkeypatch)
+    ds = LemmaDataset(cases.lemma_document(enc, "ragged"), for_training=False)
+    col = Word2TargetCollate(enc)
+    for n in (1, 5, len(ds)):
+        X = col.collate_fn([ds[i] for i in range(n)], targets=False)
+        oc, ok, steps, logits = m._decode(m._encode(X), max_steps=11, keep_logits=True)
+        assert oc.shape == (n, 11) and steps == 11 and logits.shape[0] == 11
+    kinds = {c[0] for c in lib.calls}
+    assert {"gemm", "gather", "lemma_attend", "lstm_cell"} <= kinds
