@@ -3,9 +3,10 @@
 Mirror of the reference API (cube/api.py:39-128, 183-211): `Cube().load(lang, device)`,
 `cube(text_or_Document, flavour=None) -> Document`.  Only what `Cube.__call__` dispatches AFTER
 tokenization is implemented here: `lm_helper.apply(doc)` followed by
-`Parser.process(doc, collate, num_workers=0)`.  Raw-string input needs the tokenizer stage and
-the lemmatizer is a later stage — both out of scope — so a `str` raises NotImplementedError and
-lemmas are left untouched.  Model download (api.py:150-180) needs the network and is not done:
+`Parser.process(doc, collate, num_workers=0)` and `Lemmatizer.process(doc, collate,
+num_workers=0)` (api.py:124-126; the lemmatizer is loaded when its `-trf-lemmatizer.*` files are in
+the model directory, otherwise lemmas are left untouched).  Raw-string input needs the tokenizer
+stage, which is out of scope, so a `str` raises NotImplementedError.  Model download (api.py:150-180) needs the network and is not done:
 the model directory `~/.nlpcube/3.0/<lang>` must already exist.
 """
 import os
@@ -14,9 +15,10 @@ from typing import Optional, Union
 
 import yaml
 
-from cube_amd.io_utils.config import ParserConfig
+from cube_amd.io_utils.config import LemmatizerConfig, ParserConfig
 from cube_amd.io_utils.encodings import Encodings
 from cube_amd.io_utils.objects import Document
+from cube_amd.networks.lemmatizer import Lemmatizer, Word2TargetCollate
 from cube_amd.networks.lm import LMHelperDummy, LMHelperPrecomputed
 from cube_amd.networks.parser import Parser
 from cube_amd.networks.utils import MorphoCollate
@@ -34,6 +36,17 @@ class CubeObj:
             self._lang2id[lng] = len(self._lang2id)
         self._default_lang_id = self._lang2id[g_conf["language_map"][lang]]
         self._default_lang = lang
+        # lemmatizer (api.py:82-90)
+        self._lemmatizer = None
+        path = "{0}-trf-lemmatizer".format(model_base)
+        if os.path.exists("{0}.config".format(path)):
+            config = LemmatizerConfig(filename="{0}.config".format(path))
+            encodings = Encodings()
+            encodings.load("{0}.encodings".format(path))
+            self._lemmatizer = Lemmatizer(config, encodings)
+            self._lemmatizer.load("{0}.best".format(path))
+            self._lemmatizer.to(device)
+            self._lemmatizer_collate = Word2TargetCollate(encodings)
         path = "{0}-trf-parser".format(model_base)
         config = ParserConfig(filename="{0}.config".format(path))
         if lm_helper is not None:
@@ -68,6 +81,8 @@ class CubeObj:
         del lang_id
         self._lm_helper.apply(doc)
         self._parser.process(doc, self._parser_collate, num_workers=0)
+        if self._lemmatizer is not None:
+            self._lemmatizer.process(doc, self._lemmatizer_collate, num_workers=0)
         return doc
 
 
