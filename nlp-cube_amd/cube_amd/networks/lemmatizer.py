@@ -109,6 +109,7 @@ class Lemmatizer:
         self._pk_cpu = self._pk = self._lay = self._buf = None
         self.training = False
         self.precision = "bf16x3"
+        self.max_steps = None  # None = the reference's 20 * S failsafe (lemmatizer.py:141); benches cap it
 
     # ---- reference-compatible module surface ----------------------------------------------
     def eval(self):
@@ -275,7 +276,7 @@ class Lemmatizer:
     def decode_batch(self, X):
         """-> (chars int32 [B, n], cases int32 [B, n]) arg-max sequences (NumPy), no logits kept."""
         self._require_gpu()
-        oc, ok, _, _ = self._decode(self._encode(X))
+        oc, ok, _, _ = self._decode(self._encode(X), max_steps=self.max_steps)
         return oc, ok
 
     def _strings(self, oc, ok):
@@ -294,6 +295,38 @@ class Lemmatizer:
                 s.append(ch)
             out.append("".join(s))
         return out
+
+    def process_bucketed(self, doc, collate, max_words=8192):
+        """Throughput mode, no counterpart in the reference: every distinct (word, UPOS, language) is
+        lemmatised ONCE, in batches of words of the SAME length (S = length + 2, so no pad positions
+        take part in the convolutions or the attention and a word's lemma does not depend on its
+        batch).  Lemmas therefore differ from `process` exactly where the reference's own results
+        depend on batch composition.  Words longer than 25 characters keep their lemma (the
+        reference's dataset skips them, utils.py:109-110, and then mis-assigns, lemmatizer.py:225-229)."""
+        self._require_gpu()
+        keys = {}
+        for sent in doc.sentences:
+            for w in sent.words:
+                if len(w.word) <= 25:
+                    keys.setdefault((w.word, w.upos, sent.lang_id), None)
+        by_len = {}
+        for k in keys:
+            by_len.setdefault(len(k[0]), []).append(k)
+        for n in sorted(by_len):
+            group = by_len[n]
+            for s in range(0, len(group), max_words):
+                part = group[s:s + max_words]
+                items = [{"word": k[0], "upos": k[1], "lang_id": k[2], "target": ""} for k in part]
+                batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
+                batch.pop("y_char", None)
+                batch.pop("y_case", None)
+                for k, lemma in zip(part, self._strings(*self.decode_batch(batch))):
+                    keys[k] = lemma
+        for sent in doc.sentences:
+            for w in sent.words:
+                if len(w.word) <= 25:
+                    w.lemma = keys[(w.word, w.upos, sent.lang_id)]
+        return doc
 
     def process(self, doc, collate, batch_size=4, num_workers=4):
         """reference: lemmatizer.py:185-231.  `num_workers` is accepted and ignored."""

@@ -223,3 +223,26 @@ def test_cube_api_runs_parser_then_lemmatizer(dev, tmp_path):
     m.process(b, Word2TargetCollate(lenc), num_workers=0)
     assert str(a) == str(b)
     assert any(w.lemma not in ("_", "") for s in a.sentences for w in s.words)
+
+
+def test_process_bucketed_is_batch_independent(dev):
+    """process_bucketed: equal-length batches of distinct (word, UPOS, language) keys.  Each word's
+    lemma equals what the same word gives alone in a batch of one (rows of the kernels do not
+    interact), duplicates share one result, over-long words keep their lemma."""
+    from cube_amd.networks.lemmatizer import Word2TargetCollate
+    m, cfg, enc, sd = _model("full", dev)
+    col = Word2TargetCollate(enc)
+    doc = cases.lemma_document(enc, "ragged", max_word_len=5)
+    words = [w for s in doc.sentences for w in s.words]
+    words[3].word, words[3].upos = words[0].word, words[0].upos          # a duplicate key ...
+    doc.sentences[0].lang_id = doc.sentences[1].lang_id = 2             # ... (words 0 and 3 are in sentence 0)
+    words[5].word, words[5].lemma = "y" * 30, "keep-me"
+    m.process_bucketed(doc, col, max_words=7)
+    assert words[5].lemma == "keep-me"
+    assert words[0].lemma == words[3].lemma
+    for sent in doc.sentences[:3]:
+        for w in sent.words:
+            if len(w.word) > 25:
+                continue
+            X = col.collate_fn([{"word": w.word, "upos": w.upos, "lang_id": sent.lang_id, "target": ""}], targets=False)
+            assert m._strings(*m.decode_batch(X))[0] == w.lemma
