@@ -8,8 +8,8 @@ with every tensor operation in gfx950 kernels behind the C ABI of include/cube_h
 Per batch of words: the gated char CNN encoder runs once (5 x cube_gemm_bf16 with the gate
 epilogue, language embedding folded into per-(language, tap mask) bias tables), then the attention
 Conv1d is split: its encoder half is one implicit-conv GEMM per batch, its query half (the query is
-constant along the word) is part of the per-step "query" GEMM together with the two output heads.
-A greedy step is 3 GEMMs + 3 row kernels, all asynchronous; the host looks at the device's
+constant along the word) is a per-step GEMM of 5 tap projections.
+A greedy step is 4 GEMMs (query taps, output heads, LSTM layers 0 and 1) + 3 row kernels, all asynchronous; the host looks at the device's
 finished-word counter every `CHECK_EVERY` steps instead of every step (lemmatizer.py:139,161-163).
 """
 import ctypes
@@ -56,6 +56,7 @@ class Word2TargetCollate:
         self._codes = {}
 
     def _code(self, ch):
+        """(char id, case id) of one character; case: 1 symbol, 2 upper, 3 lower (utils.py:186-196)."""
         hit = self._codes.get(ch)
         if hit is None:
             lo = ch.lower()
@@ -63,24 +64,43 @@ class Word2TargetCollate:
             hit = self._codes[ch] = (self._encodings.char2int.get(lo, self._encodings.char2int["<UNK>"]), case)
         return hit
 
-    def _fill(self, texts, width, first, last):
+    def _tables(self, cps):
+        """code point -> (char id, case id) arrays, grown on demand; the per-character rule runs once
+        per distinct character, the batch is then filled by fancy indexing."""
+        top = int(cps.max()) + 1 if len(cps) else 1
+        tab = getattr(self, "_cp_tab", None)
+        if tab is None or tab.shape[1] < top:
+            new = np.full((2, max(top, 256)), -1, dtype=np.int64)
+            if tab is not None:
+                new[:, :tab.shape[1]] = tab
+            self._cp_tab = tab = new
+        for cp in np.unique(cps[tab[0, cps] < 0]).tolist():
+            tab[:, cp] = self._code(chr(cp))
+        return tab
+
+    def _fill(self, texts, first, last):
+        """[n, longest + 1 (+1 with a start symbol)] character / case ids: [first,] text, last, zeros."""
         n = len(texts)
+        lens = np.fromiter(map(len, texts), dtype=np.int64, count=n)
+        off = 0 if first is None else 1
+        width = int(lens.max()) + 1 + off
         chars = np.zeros((n, width), dtype=np.int64)
         case = np.zeros((n, width), dtype=np.int64)
-        for i, t in enumerate(texts):
-            if first is not None:
-                chars[i, 0] = first
-            p = 0 if first is None else 1
-            for ch in t:
-                chars[i, p], case[i, p] = self._code(ch)
-                p += 1
-            chars[i, p] = last
+        cps = np.frombuffer("".join(texts).encode("utf-32-le", "surrogatepass"), dtype=np.uint32).astype(np.int64)
+        tab = self._tables(cps)
+        wi = np.repeat(np.arange(n), lens)
+        pi = np.arange(len(wi)) - np.repeat(np.cumsum(lens) - lens, lens) + off
+        chars[wi, pi] = tab[0, cps]
+        case[wi, pi] = tab[1, cps]
+        if first is not None:
+            chars[:, 0] = first
+        chars[np.arange(n), lens + off] = last
         return chars, case
 
     def collate_fn(self, batch, targets=True):
         enc = self._encodings
         words = [e["word"] for e in batch]
-        x_char, x_case = self._fill(words, max(len(w) for w in words) + 2, self._start_index, self._stop_index)
+        x_char, x_case = self._fill(words, self._start_index, self._stop_index)
         unk = enc.upos2int["<UNK>"]
         out = {
             "x_char": torch.from_numpy(x_char), "x_case": torch.from_numpy(x_case),
@@ -89,7 +109,7 @@ class Word2TargetCollate:
         }
         if targets:
             tg = [e["target"] for e in batch]
-            y_char, y_case = self._fill(tg, max(len(t) for t in tg) + 1, None, self._eol)
+            y_char, y_case = self._fill(tg, None, self._eol)
             out["y_char"], out["y_case"] = torch.from_numpy(y_char), torch.from_numpy(y_case)
         return out
 
@@ -204,9 +224,10 @@ class Lemmatizer:
         cs = buf.get("cells", 2 * B, D, torch.float32)
         cs[:2 * B * D].zero_()
         c0, c1 = cs[:B * D], cs[B * D:2 * B * D]
-        l0, l1, qq = pk["lstm0"], pk["lstm1"], pk["query"]
+        l0, l1, qq, hh = pk["lstm0"], pk["lstm1"], pk["query"], pk["heads"]
         gates = buf.get("gates", B, l0["N"], torch.float32)
-        q = buf.get("q", B, qq["N"], torch.float32)
+        ld_q = lay.q_w
+        q = buf.get("q", B, ld_q, torch.float32)
         out = torch.zeros((2, B, max(limit, 1)), dtype=torch.int32, device=dev)
         flags = torch.zeros(B + 1, dtype=torch.int32, device=dev)
         logits = torch.zeros((limit, B, lay.n_char + lay.n_case), dtype=torch.float32, device=dev) if keep_logits else None
@@ -224,7 +245,7 @@ class Lemmatizer:
                                          lay.xd_h1, xd.hi.data_ptr(), lo(xd.lo), lay.xd_c1, st), "cube_lstm_cell")
 
         a = hip.LemmaAttendArgs()
-        a.q, a.ld_q, a.taps, a.P, a.ld_tap = q.data_ptr(), qq["N"], pk["att_enc"]["taps"], lay.P, lay.ld_tap
+        a.q, a.ld_q, a.taps, a.P, a.ld_tap = q.data_ptr(), ld_q, pk["att_enc"]["taps"], lay.P, lay.ld_tap
         a.col_char, a.n_char, a.col_case, a.n_case = lay.q_char, lay.n_char, lay.q_case, lay.n_case
         a.v, a.e_enc, a.ld_e = pk["att_v"].data_ptr(), ed["e_enc"].data_ptr(), ed["ld_e"]
         a.enc, a.enc_lo, a.ld_enc, a.C = ed["enc"].hi.data_ptr(), lo(ed["enc"].lo), lay.enc_w, lay.enc_c
@@ -240,10 +261,14 @@ class Lemmatizer:
         lstm()
         steps = 0
         for s in range(limit + 1):
-            hip.gemm(xd, ld_x, B, qq["K"], qq["W"], qq["N"], qq["bias"], hip.EPI_F32, out0=q, ldo0=qq["N"], n_valid=qq["N"],
-                     a_col=lay.xd_h1, stream=st)
+            if s < limit:   # tap projections of the query (cell state c1) for this step's attention
+                hip.gemm(xd, ld_x, B, qq["K"], qq["W"], qq["N"], qq["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, n_valid=qq["N"],
+                         a_col=lay.xd_c1, stream=st)
+            if s > 0:       # output heads on h1 of the previous step
+                hip.gemm(xd, ld_x, B, hh["K"], hh["W"], hh["N"], hh["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, col0=lay.q_char,
+                         n_valid=hh["N"], a_col=lay.xd_h1, stream=st)
             if keep_logits and s > 0:
-                logits[s - 1].copy_(q[:B * qq["N"]].view(B, qq["N"])[:, lay.q_char:lay.q_char + lay.n_char + lay.n_case])
+                logits[s - 1].copy_(q[:B * ld_q].view(B, ld_q)[:, lay.q_char:lay.q_char + lay.n_char + lay.n_case])
             a.step, a.attend = s, int(s < limit)
             hip.check(lib.cube_lemma_attend(ctypes.byref(a), st), "cube_lemma_attend")
             steps = s
@@ -280,20 +305,39 @@ class Lemmatizer:
         return oc, ok
 
     def _strings(self, oc, ok):
-        chars = self._encodings.characters
-        out = []
-        for row_c, row_k in zip(oc.tolist(), ok.tolist()):
-            s = []
-            for c, k in zip(row_c, row_k):
-                if c == self._eol:
-                    break
-                ch = chars[c]  # IndexError for the stop index, like the reference (lemmatizer.py:217)
-                if k == 2:
-                    ch = ch.upper()
-                elif k == 3:
-                    ch = ch.lower()
-                s.append(ch)
-            out.append("".join(s))
+        """arg-max ids -> lemma strings (lemmatizer.py:210-224): characters up to the first EOL, the case
+        head upper-/lower-cases each one.  Rows whose characters all map to single code points (all but
+        '<PAD>', '<UNK>' and letters whose upper case is a sequence) are assembled as one UTF-32 buffer."""
+        tabs = getattr(self, "_char_tabs", None)
+        if tabs is None:
+            chars = self._encodings.characters
+            obj = tuple(np.array([f(c) for c in chars] + [""], dtype=object) for f in (str, str.upper, str.lower))
+            single = np.array([all(len(t[i]) == 1 for t in obj) for i in range(len(chars))] + [True])
+            cps = tuple(np.array([ord(x) if len(x) == 1 else 0 for x in t.tolist()], dtype=np.uint32) for t in obj)
+            tabs = self._char_tabs = (obj, cps, single)
+        obj, cps, single = tabs
+        pad = len(single) - 1
+        B, n = oc.shape
+        is_eol = oc == self._eol
+        end = np.where(is_eol.any(axis=1), is_eol.argmax(axis=1), n) if n else np.zeros(B, dtype=np.int64)
+        live = np.arange(n)[None, :] < end[:, None]
+        if (oc[live] >= pad).any():
+            raise IndexError("list index out of range")  # the stop index has no character (lemmatizer.py:217)
+        idx = np.where(live, oc, pad)
+        fast = single[idx].all(axis=1)
+        out = [None] * B
+        rows = np.where(fast)[0]
+        if len(rows):
+            i, k, lv = idx[rows], ok[rows], live[rows]
+            cp = np.where(k == 2, cps[1][i], np.where(k == 3, cps[2][i], cps[0][i]))
+            text = cp[lv].astype("<u4").tobytes().decode("utf-32-le", "surrogatepass")
+            pos = 0
+            for r, e in zip(rows.tolist(), end[rows].tolist()):
+                out[r] = text[pos:pos + e]
+                pos += e
+        for r in np.where(~fast)[0].tolist():
+            i, k = idx[r, :end[r]], ok[r, :end[r]]
+            out[r] = "".join(np.where(k == 2, obj[1][i], np.where(k == 3, obj[2][i], obj[0][i])).tolist())
         return out
 
     def process_bucketed(self, doc, collate, max_words=8192):

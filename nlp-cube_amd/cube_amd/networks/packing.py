@@ -412,9 +412,11 @@ class LemmaLayout:
         self.xd_h1 = self.xd_h0 + p32(self.D)
         self.xd_c1 = self.xd_h1 + p32(self.D)
         self.xd_w = self.xd_c1 + p32(self.D)
+        # Q (f32, per step): [5 tap projections of the query, ld_tap each, pad to 128 | char logits | case logits]
         self.ld_tap = p8(self.P)
-        self.q_char = 5 * self.ld_tap
+        self.q_char = p128(5 * self.ld_tap)
         self.q_case = self.q_char + self.n_char
+        self.q_w = self.q_char + p128(self.n_char + self.n_case)
 
     def xe0_perm(self):
         """XE0 column -> input channel of the first conv ([char, case, upos, lang], lemmatizer.py:92-98,113)."""
@@ -456,19 +458,22 @@ def pack_lemmatizer(sd, cfg, n_chars):
     enc_perm = lay.enc_perm()
     pk["att_enc"] = pack_conv_plain(wa, ba, np.where(enc_perm >= 0, enc_perm + D, -1))
     pk["att_v"] = sd["_attention.v"].float().contiguous()
-    # ... the query part per step, in one GEMM with the output heads: A = [h1 | c1]
+    # ... the query part per step: 5 tap projections of the query (= cell state c1, lemmatizer.py:144)
     KD = p32(D)
-    nq = p128(lay.q_case + lay.n_case)
-    Wq, bq = _dense(nq, 2 * KD), torch.zeros(nq, dtype=torch.float32)
+    Wt = _dense(lay.q_char, KD)
     for k in range(wa.shape[2]):
-        Wq[k * lay.ld_tap:k * lay.ld_tap + P, KD:KD + D] = wa[:, :D, k]          # query = cell state c1
-    Wq[lay.q_char:lay.q_char + lay.n_char, :D] = sd["_output_char.linear_layer.weight"].float()
-    bq[lay.q_char:lay.q_char + lay.n_char] = sd["_output_char.linear_layer.bias"].float()
-    Wq[lay.q_case:lay.q_case + lay.n_case, :D] = sd["_output_case.linear_layer.weight"].float()
-    bq[lay.q_case:lay.q_case + lay.n_case] = sd["_output_case.linear_layer.bias"].float()
-    pk["query"] = dict(W=_bf16(Wq), bias=bq, K=2 * KD, N=nq)
+        Wt[k * lay.ld_tap:k * lay.ld_tap + P, :D] = wa[:, :D, k]
+    pk["query"] = dict(W=_bf16(Wt), bias=torch.zeros(lay.q_char, dtype=torch.float32), K=KD, N=lay.q_char)
+    # the two output heads read h1
+    nh = lay.q_w - lay.q_char
+    Wh, bh = _dense(nh, KD), torch.zeros(nh, dtype=torch.float32)
+    Wh[:lay.n_char, :D] = sd["_output_char.linear_layer.weight"].float()
+    bh[:lay.n_char] = sd["_output_char.linear_layer.bias"].float()
+    Wh[lay.n_char:lay.n_char + lay.n_case, :D] = sd["_output_case.linear_layer.weight"].float()
+    bh[lay.n_char:lay.n_char + lay.n_case] = sd["_output_case.linear_layer.bias"].float()
+    pk["heads"] = dict(W=_bf16(Wh), bias=bh, K=KD, N=nh)
     # decoder LSTM: layer 0 reads [ctx | prev char | h0], layer 1 reads [h0 | h1]
-    ng = p128(4 * D)
+    ng = (4 * D + 255) // 256 * 256   # multiples of 256 columns: large batches run on the 256x256 tiles
     vk = torch.from_numpy(np.where(enc_perm >= 0)[0])
     src = torch.from_numpy(enc_perm[enc_perm >= 0])
     w_ih, w_hh = sd["_decoder.weight_ih_l0"].float(), sd["_decoder.weight_hh_l0"].float()

@@ -75,3 +75,38 @@ def test_dataset_skips_long_words_like_the_reference():
     doc = cases.lemma_document(enc, "single")
     doc.sentences[0].words[0].word = "x" * 26
     assert lo.dataset(doc) == []
+
+
+def test_host_collate_and_strings_match_oracle():
+    """cube_amd's vectorised Word2TargetCollate / lemma string assembly == the literal restatements."""
+    from cube_amd.networks.lemmatizer import LemmaDataset, Lemmatizer, Word2TargetCollate
+    cfg, enc, sd = cases.lemmatizer_model(cases.LEMMA_SMALL)
+    doc = cases.lemma_document(enc, "g6")
+    for s in doc.sentences:
+        for w in s.words:
+            w.lemma = w.word[::-1].lower()
+    ds = LemmaDataset(doc, for_training=False)
+    items = [ds[i] for i in range(len(ds))]
+    assert [e["word"] for e in items] == [e["word"] for e in lo.dataset(doc)]
+    X = Word2TargetCollate(enc).collate_fn(items)
+    ref = lo.collate(items, enc)
+    for k in ref:
+        assert X[k].dtype == torch.int64 and np.array_equal(X[k].numpy(), ref[k].numpy()), k
+    # targets (utils.py:200-213): characters of the lemma, then EOL, zero padded
+    C = len(enc.char2int)
+    T = max(len(e["target"]) for e in items) + 1
+    assert tuple(X["y_char"].shape) == (len(items), T)
+    for i, e in enumerate(items):
+        want = [enc.char2int.get(ch.lower(), 1) for ch in e["target"]] + [C]
+        assert X["y_char"][i, :len(want)].tolist() == want and not X["y_char"][i, len(want):].any()
+        assert X["y_case"][i, :len(e["target"])].tolist() == [lo._case(ch) for ch in e["target"]]
+    # strings: random ids including <PAD>/<UNK> (multi-character entries) and every case id
+    rng = np.random.default_rng(0)
+    oc = rng.integers(0, C + 1, size=(500, 12)).astype(np.int32)
+    ok = rng.integers(0, 4, size=(500, 12)).astype(np.int32)
+    got = Lemmatizer(cfg, enc)._strings(oc, ok)
+    onehot_c = torch.nn.functional.one_hot(torch.from_numpy(oc).long(), C + 2).float()
+    onehot_k = torch.nn.functional.one_hot(torch.from_numpy(ok).long(), 4).float()
+    assert got == lo.OracleLemmatizer(cfg, enc, sd).lemmas(onehot_c, onehot_k)
+    with pytest.raises(IndexError):
+        Lemmatizer(cfg, enc)._strings(np.full((1, 3), C + 1, dtype=np.int32), np.zeros((1, 3), dtype=np.int32))
