@@ -85,16 +85,30 @@ __global__ __launch_bounds__(256) void lemma_attend_kernel(cube_lemma_attend_arg
   const float v0 = j0 < a.P ? a.v[j0] : 0.0f, v1 = j1 < a.P ? a.v[j1] : 0.0f;
   const int half = a.taps / 2;
   const float* ee = a.e_enc + (size_t)b * a.S * a.ld_e;
-  for (int t = 0; t < a.S; ++t) {
-    float p0 = j0 < a.P ? ee[(size_t)t * a.ld_e + j0] : 0.0f;
-    float p1 = j1 < a.P ? ee[(size_t)t * a.ld_e + j1] : 0.0f;
+  // four positions per iteration: their loads and wave reductions are independent and overlap
+  for (int t0 = 0; t0 < a.S; t0 += 4) {
+    float part[4];
 #pragma unroll
-    for (int k = 0; k < ATT_MAX_TAPS; ++k) {
-      const int src = t + k - half;
-      if (k < a.taps && src >= 0 && src < a.S) { p0 += hq0[k]; p1 += hq1[k]; }
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u;
+      const bool on = t < a.S;
+      float p0 = (on && j0 < a.P) ? ee[(size_t)t * a.ld_e + j0] : 0.0f;
+      float p1 = (on && j1 < a.P) ? ee[(size_t)t * a.ld_e + j1] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < ATT_MAX_TAPS; ++k) {
+        const int src = t + k - half;
+        if (k < a.taps && src >= 0 && src < a.S) { p0 += hq0[k]; p1 += hq1[k]; }
+      }
+      part[u] = v0 * tanhf_(p0) + v1 * tanhf_(p1);
     }
-    const float s = wave_sum(v0 * tanhf_(p0) + v1 * tanhf_(p1));
-    se[wave][t] = s;  // every lane holds the sum; same value to the same address
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (t0 + u < a.S) se[wave][t0 + u] = part[u];  // every lane holds the sum; same value to the same address
   }
   // ---- soft-max over all S positions (pads included, as the reference does)
   float m = -INFINITY;
@@ -115,27 +129,28 @@ __global__ __launch_bounds__(256) void lemma_attend_kernel(cube_lemma_attend_arg
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint16_t* eh = (const uint16_t*)a.enc + (size_t)b * a.S * a.ld_enc + c0;
     const uint16_t* el = a.enc_lo ? (const uint16_t*)a.enc_lo + (size_t)b * a.S * a.ld_enc + c0 : nullptr;
-    for (int t = 0; t < a.S; ++t) {
-      const float w = se[wave][t] * z;
-      const uint4 h = *(const uint4*)(eh + (size_t)t * a.ld_enc);
-      const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
-      float f[8];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    for (int t0 = 0; t0 < a.S; t0 += 4) {   // 4 rows (8 16-byte loads) in flight per lane
+      uint4 h[4], l[4];
+      float w[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __uint_as_float(hw[i] << 16);
-        f[2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u);
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        const bool on = t < a.S;
+        w[u] = on ? se[wave][t] * z : 0.0f;
+        h[u] = on ? *(const uint4*)(eh + (size_t)t * a.ld_enc) : zero4;
+        l[u] = (on && el) ? *(const uint4*)(el + (size_t)t * a.ld_enc) : zero4;
       }
-      if (el) {
-        const uint4 l = *(const uint4*)(el + (size_t)t * a.ld_enc);
-        const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t hw[4] = {h[u].x, h[u].y, h[u].z, h[u].w};
+        const uint32_t lw[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f[2 * i] += __uint_as_float(lw[i] << 16);
-          f[2 * i + 1] += __uint_as_float(lw[i] & 0xffff0000u);
+          acc[2 * i] += w[u] * (__uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16));
+          acc[2 * i + 1] += w[u] * (__uint_as_float(hw[i] & 0xffff0000u) + __uint_as_float(lw[i] & 0xffff0000u));
         }
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += w * f[i];
     }
     uint32_t ph[4], pl[4];
 #pragma unroll

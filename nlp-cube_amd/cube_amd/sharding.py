@@ -42,21 +42,27 @@ class _Slice:
         self.sentences = doc.sentences[lo:hi]
 
 
-def process_sharded(parser, doc, collate, batch_size=4, rank=None, world_size=None, gather=True):
+def process_sharded(parser, doc, collate, batch_size=4, rank=None, world_size=None, gather=True,
+                    lemmatizer=None, lemmatizer_collate=None):
     """Run `parser.process` on this rank's shard of `doc`; with gather=True rank 0 ends up with
-    every word's head/label/upos/xpos/attrs filled (other ranks: their own shard only)."""
+    every word's head/label/upos/xpos/attrs filled (other ranks: their own shard only).
+    With a `lemmatizer`, the rank also lemmatises its shard (`process_bucketed`: one decode per distinct
+    (word, UPOS, language), equal-length batches — a word's lemma does not depend on its batch, so the
+    result does not depend on the sharding either) and the lemma column travels with the others."""
     rank = dist.get_rank() if rank is None else rank
     world_size = dist.get_world_size() if world_size is None else world_size
     lo, hi = shard_bounds(len(doc.sentences), rank, world_size, batch_size)
     if hi > lo:
         parser.process(_Slice(doc, lo, hi), collate, batch_size=batch_size, num_workers=0)
+        if lemmatizer is not None:
+            lemmatizer.process_bucketed(_Slice(doc, lo, hi), lemmatizer_collate)
     if gather and world_size > 1:
-        mine = [[(int(w.head), w.label, w.upos, w.xpos, w.attrs) for w in s.words] for s in doc.sentences[lo:hi]]
+        mine = [[(int(w.head), w.label, w.upos, w.xpos, w.attrs, w.lemma) for w in s.words] for s in doc.sentences[lo:hi]]
         parts = [None] * world_size if rank == 0 else None
         dist.gather_object((lo, hi, mine), parts, dst=0)
         if rank == 0:
             for plo, phi, rows in parts:
                 for s, srow in zip(doc.sentences[plo:phi], rows):
-                    for w, (h, lab, u, x, a) in zip(s.words, srow):
-                        w.head, w.label, w.upos, w.xpos, w.attrs = h, lab, u, x, a
+                    for w, (h, lab, u, x, a, lem) in zip(s.words, srow):
+                        w.head, w.label, w.upos, w.xpos, w.attrs, w.lemma = h, lab, u, x, a, lem
     return doc

@@ -39,13 +39,23 @@ class _FakeParser:
         return doc
 
 
+class _FakeLemmatizer:
+    """a pure function of (word, UPOS, language), as Lemmatizer.process_bucketed is."""
+
+    def process_bucketed(self, doc, collate, max_words=8192):
+        for s in doc.sentences:
+            for w in s.words:
+                w.lemma = "%s|%s|%d" % (w.word.lower(), w.upos, s.lang_id)
+        return doc
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     enc = synth.make_encodings(n_chars=40, n_words=50, n_upos=6, n_xpos=7, n_attrs=8, n_labels=9, num_langs=2)
     doc = synth.make_document(enc, [3 + (i * 7) % 11 for i in range(37)], seed=5, ext_word_emb=(4,))
-    process_sharded(_FakeParser(), doc, None, batch_size=4)
+    process_sharded(_FakeParser(), doc, None, batch_size=4, lemmatizer=_FakeLemmatizer())
     if rank == 0:
         with open(out, "w", encoding="utf-8") as f:
             f.write(str(doc))
@@ -59,6 +69,8 @@ def test_two_rank_gloo_run_equals_single_process(tmp_path):
     enc = synth.make_encodings(n_chars=40, n_words=50, n_upos=6, n_xpos=7, n_attrs=8, n_labels=9, num_langs=2)
     doc = synth.make_document(enc, [3 + (i * 7) % 11 for i in range(37)], seed=5, ext_word_emb=(4,))
     _FakeParser().process(doc, None, batch_size=4)
+    _FakeLemmatizer().process_bucketed(doc, None)
+    assert all(w.lemma != "_" for s in doc.sentences for w in s.words)
     assert open(out, encoding="utf-8").read() == str(doc)
 
 
