@@ -38,7 +38,7 @@ CONFIGS = {1: dict(B=256, L=32, name="en parser+tagger B=256 x L=32 (BASELINE co
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def build_model_and_batches(cfg_id, n_batches, rank, device, precision):
+def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300,)):
     from cube_amd import synth
     from cube_amd.io_utils.config import ParserConfig
     from cube_amd.networks.parser import Parser
@@ -46,8 +46,8 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision):
     c = CONFIGS[cfg_id]
     cfg = ParserConfig()
     enc = synth.make_encodings()
-    sd = synth.make_parser_state_dict(cfg, enc, [300], seed=1234)
-    p = Parser(cfg, enc, language_codes=synth.EN_LANGUAGE_CODES, ext_word_emb=[300])
+    sd = synth.make_parser_state_dict(cfg, enc, list(ext), seed=1234)
+    p = Parser(cfg, enc, language_codes=synth.EN_LANGUAGE_CODES, ext_word_emb=list(ext))
     if precision:
         p.precision = precision
     p.load_state_dict(sd)
@@ -58,13 +58,13 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision):
         from cube_amd.sharding import bucketed_batches
         rng = np.random.default_rng(3000 + rank)
         lens = np.clip(np.round(rng.normal(22, 10, size=c["n_sent"])), 3, 80).astype(np.int64)
-        doc = synth.make_document(enc, lens, seed=3000 + rank, ext_word_emb=(300,))
+        doc = synth.make_document(enc, lens, seed=3000 + rank, ext_word_emb=tuple(ext))
         for idx in bucketed_batches(lens, 8192):
             X = col.collate_fn([doc.sentences[i] for i in idx], targets=False)
             batches.append(p._prepare(X))
         return p, cfg, enc, sd, batches, [doc]
     for i in range(n_batches):
-        doc = synth.make_document(enc, [c["L"]] * c["B"], seed=1000 * (rank + 1) + i, ext_word_emb=(300,))
+        doc = synth.make_document(enc, [c["L"]] * c["B"], seed=1000 * (rank + 1) + i, ext_word_emb=tuple(ext))
         X = col.collate_fn(doc.sentences)
         X.pop("y_upos")
         batches.append(p._prepare(X))
@@ -92,13 +92,13 @@ def run_steps(p, batches, n):
     return out
 
 
-def cpu_baseline(cfg, enc, sd, docs, batch_size, budget_s=15.0):
+def cpu_baseline(cfg, enc, sd, docs, batch_size, budget_s=15.0, ext=(300,)):
     """The oracle (CPU restatement of the reference path, fp32) on a bounded sample: batches of
     `batch_size` sentences of the bench workload until ~budget_s seconds of CPU work are done."""
     from oracle import parser_oracle
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
-    net = parser_oracle.OracleParser(cfg, enc, sd, [300], quant="fp32")
+    net = parser_oracle.OracleParser(cfg, enc, sd, list(ext), quant="fp32")
     sents = [s for d in docs for s in d.sentences]
     done = 0
     t0 = time.perf_counter()
@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--precision", default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ext", default="1x300", help="external embeddings per word as KxE: 1x300 (fastText-like, the "
+                    "BASELINE config) or 13x768 (xlm-roberta-base-like, SURVEY 8d secondary input)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +139,9 @@ def main():
 
     c = CONFIGS[args.config]
     n_batches = 4
-    p, cfg, enc, sd, batches, docs = build_model_and_batches(args.config, n_batches, rank, device, args.precision)
+    k, e = args.ext.lower().split("x")
+    ext = (int(e),) * int(k)
+    p, cfg, enc, sd, batches, docs = build_model_and_batches(args.config, n_batches, rank, device, args.precision, ext)
 
     def barrier():
         if dist:
@@ -199,12 +203,12 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": p.precision,
         "data": "synthetic (SURVEY.md 8d: random-init weights seed 1234, synthetic vocabulary and sentences)",
-        "config": {"workload": c["name"], "B": c["B"], "L": c["L"], "padded_W": bt["W"], "ext_emb": [300],
+        "config": {"workload": c["name"], "B": c["B"], "L": c["L"], "padded_W": bt["W"], "ext_emb": list(ext),
                    "sharding": "sentences sharded across ranks, no collective on the data path"},
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(cfg, enc, sd, docs, {1: 32, 2: 8, 3: 32}[args.config])
+        out["cpu_baseline"] = cpu_baseline(cfg, enc, sd, docs, {1: 32, 2: 8, 3: 32}[args.config], ext=ext)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -13,6 +13,8 @@ TINY = dict(name="tiny", seed=11, ext=(12, 8), dims=dict(char_emb_size=16, char_
             vocab=dict(n_chars=60, n_words=300, n_upos=9, n_xpos=14, n_attrs=20, n_labels=11, num_langs=3))
 # full dims = default ParserConfig, SURVEY.md §8d vocabulary
 FULL = dict(name="full", seed=1234, ext=(300,), dims={}, vocab={})
+# SURVEY §8d secondary input: 13 LM layers of 768 values per word ("transformer-like", lm.py:141-208)
+FULL_K13 = dict(name="full_k13", seed=1234, ext=(768,) * 13, dims={}, vocab={})
 TINY_TAGGER = dict(name="tiny_tagger", seed=12, ext=(12,), dims=dict(char_emb_size=16, char_filter_size=32,
                    char_layers=2, word_emb_size=24, lang_emb_size=8, cnn_filter=32, cnn_layers=3,
                    external_proj_size=5), vocab=TINY["vocab"])

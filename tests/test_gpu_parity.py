@@ -328,6 +328,26 @@ def test_parser_bf16x3_matches_reference(dev, golden_dir, case, doc_key, fixture
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
 
 
+def test_parser_transformer_like_embeddings_match_oracle(dev):
+    """K = 13 external-embedding layers of 768 values per word (what LMHelperHF hands over for
+    xlm-roberta-base, lm.py:141-208; SURVEY §8d secondary input) at full model dims, against the fp32
+    oracle: 13 MLPs accumulated and averaged (parser.py:130-138), everything downstream as usual."""
+    p, r, e, _ = _run_case(dev, cases.FULL_K13, "ragged", "bf16x3")
+    assert len(p._pk["ext"]) == 13
+    sl = r["bt"]["lens"].cpu().numpy()
+    arc = r["arc_logits"].cpu().numpy()
+    assert _rel(arc, e["arc_logits"]) < REL_TOL
+    assert _rel(r["upos_logits"].cpu().numpy(), e["upos_logits"]) < REL_TOL
+    mask = np.arange(arc.shape[1])[None, :] < sl[:, None]
+    heads = r["heads"].cpu().numpy()
+    exp = np.zeros_like(heads)
+    for b, h in enumerate(e["heads"]):
+        exp[b, :len(h)] = h
+    assert (heads[mask] == exp[mask]).mean() >= 0.999
+    same = mask & (heads == exp)
+    assert _rel(r["label_logits"].cpu().numpy()[same], e["label_logits"][same]) < REL_TOL
+
+
 @pytest.mark.parametrize("case,doc_key", [(cases.TINY, "equal"), (cases.TINY, "ragged"), (cases.TINY, "single")])
 def test_parser_bf16_single_pass_matches_bf16_oracle(dev, case, doc_key):
     """Single-pass bf16 mode against the oracle's bf16 arithmetic contract (small model: the
