@@ -66,8 +66,9 @@ enum {
  * CUBE_EPI_GATE: N = 2*half output channels packed so that column
  *   n = nb*128 + wc*64 + part*32 + j  holds channel (part ? half : 0) + nb*64 + wc*32 + j;
  * g = tanh(C_a) * sigmoid(C_b) per channel ch.  Then
- *   res (optional) res_mode 0: res[r,ch]  = g     1: res[r,ch] += g     2: res[r,ch] += 2g
- *   out0 (bf16, optional): [row, col0+ch] = g
+ *   res (optional) res_mode 0: res[r,ch]  = g     1, 3: res[r,ch] += g     2: res[r,ch] += 2g
+ *   out0 (bf16, optional): [row, col0+ch] = g     (res_mode 3: = res_after, the running sum — the
+ *                          tokenizer feeds every layer the sum of all previous gates, tokenizer.py:116-122)
  *   out1/out2 (bf16, optional): [row, col+ch] = res_after + g   (x + res of the reference)
  *
  * Broadcast input channels folded into the bias (CUBE_EPI_GATE only).  The reference

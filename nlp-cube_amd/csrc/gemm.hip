@@ -402,10 +402,11 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         const int row = orow_lds[wrow0 - m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
         if (row >= 0 && ch_ok) {
           const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
-          if (out0) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
+          if (out0 && res_mode != 3) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
           if (!res) continue;  // plain gated layer: no residual stream
           const float rs = rv[r] + (res_mode == 2 ? 2.0f * g : g);
           res[(size_t)row * p.ld_res + ch] = rs;
+          if (out0 && res_mode == 3) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, rs);
           if (p.out1) store_bf16(p.out1, p.out1_lo, (size_t)row * p.ldo1 + p.col1 + ch, rs + g);
           if (p.out2) store_bf16(p.out2, p.out2_lo, (size_t)row * p.ldo2 + p.col2 + ch, rs + g);
         }
@@ -564,7 +565,8 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
       if (a->res && a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs res[M, >=%d]", half);
       if (!a->res && (a->out1 || a->out2)) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: out1/out2 (x + res) need res");
       if (!a->res && !a->out0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue without any output");
-      if (a->res_mode < 0 || a->res_mode > 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: res_mode=%d", a->res_mode);
+      if (a->res_mode < 0 || a->res_mode > 3 || (a->res_mode == 3 && !a->res))
+        CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: res_mode=%d", a->res_mode);
       if (a->rowmap) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: rowmap is not supported by the gate epilogue");
       if (a->out0 && a->ldo0 < a->col0 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
       if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out1/ldo1");

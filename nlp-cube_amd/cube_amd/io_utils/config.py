@@ -109,3 +109,20 @@ class LemmatizerConfig(Config):
         self._valid = True
         if filename is not None:
             self.load(filename)
+
+
+class TokenizerConfig(Config):
+    """reference: cube/io_utils/config.py:81-101"""
+
+    def __init__(self, filename=None, verbose=False):
+        super().__init__()
+        self.cnn_filter = 512
+        self.lang_emb_size = 100
+        self.cnn_layers = 5
+        self.rnn_size = 50
+        self.rnn_layers = 2
+        self.external_proj_size = 2
+        self.no_space_lang = False
+        if filename is not None:
+            self.load(filename)
+        self._valid = True

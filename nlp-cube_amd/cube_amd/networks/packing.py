@@ -197,22 +197,29 @@ class Layout:
         return np.asarray(perm)
 
 
+def pack_wordgram(sd, prefix, n_layers, char_emb, case_emb, lang, half):
+    """WordGram (modules.py:424-448): embedding tables, gated char convs (`x + skip` doubling folded into
+    layers >= 1, language channels into bias tables), layer-0 look-up tables, `_pre_out`."""
+    pk = {}
+    pk["tok_emb"] = pack_table(sd[prefix + "._tok_emb.weight"])
+    pk["case_emb"] = pack_table(sd[prefix + "._case_emb.weight"])
+    pk["wn_lang_emb"] = pack_table(sd[prefix + "._lang_emb.weight"])
+    pk["char_convs"] = []
+    wn_lang = sd[prefix + "._lang_emb.weight"].float()
+    for l in range(n_layers):
+        cin = char_emb + case_emb if l == 0 else half  # then come the lang channels
+        pk["char_convs"].append(pack_gated_conv(sd, "%s._convolutions_char.%d" % (prefix, l), np.arange(cin),
+                                                double_first=half if l > 0 else 0,
+                                                bcast=(cin + np.arange(lang), wn_lang)))
+    pk["char_l0"] = pack_conv0_tables(sd, prefix + "._convolutions_char.0", sd[prefix + "._tok_emb.weight"],
+                                      sd[prefix + "._case_emb.weight"], wn_lang)
+    pk["char_pre_out"] = pack_linear(sd[prefix + "._pre_out.linear_layer.weight"], sd[prefix + "._pre_out.linear_layer.bias"])
+    return pk
+
+
 def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
     """Pieces shared by Parser and Tagger: WordGram, ext MLPs, word-level conv stack, aux heads."""
-    pk = {}
-    pk["tok_emb"] = pack_table(sd["_word_net._tok_emb.weight"])
-    pk["case_emb"] = pack_table(sd["_word_net._case_emb.weight"])
-    pk["wn_lang_emb"] = pack_table(sd["_word_net._lang_emb.weight"])
-    pk["char_convs"] = []
-    wn_lang = sd["_word_net._lang_emb.weight"].float()
-    for l in range(cfg.char_layers):
-        cin = lay.char_emb + lay.case_emb if l == 0 else lay.char_half  # then come the lang channels
-        pk["char_convs"].append(pack_gated_conv(sd, "_word_net._convolutions_char.%d" % l, np.arange(cin),
-                                                double_first=lay.char_half if l > 0 else 0,
-                                                bcast=(cin + np.arange(lay.lang), wn_lang)))
-    pk["char_l0"] = pack_conv0_tables(sd, "_word_net._convolutions_char.0", sd["_word_net._tok_emb.weight"],
-                                      sd["_word_net._case_emb.weight"], wn_lang)
-    pk["char_pre_out"] = pack_linear(sd["_word_net._pre_out.linear_layer.weight"], sd["_word_net._pre_out.linear_layer.bias"])
+    pk = pack_wordgram(sd, "_word_net", cfg.char_layers, lay.char_emb, lay.case_emb, lay.lang, lay.char_half)
     pk["ext"] = []
     for i, e in enumerate(ext_dims):
         h1 = pack_linear(sd["_ext_proj.%d._h1.linear_layer.weight" % i], sd["_ext_proj.%d._h1.linear_layer.bias" % i])

@@ -69,6 +69,7 @@ class _HipNet:
 
     def __init__(self, config, encodings, language_codes=None, ext_word_emb=0):
         self._config = config
+        self._char_layers = getattr(config, "char_layers", 3)  # WordGram's default (modules.py:426)
         self._encodings = encodings
         if not isinstance(ext_word_emb, (list, tuple)):
             ext_word_emb = [ext_word_emb]
@@ -225,7 +226,7 @@ class _HipNet:
         min(W, len_g + 2*(n-k)) rows per word of group g, groups one after the other.
         -> order (sorted word -> original word), per-layer cube_conv_groups, rows per layout,
         word_rows [n, N] (first row of sorted word i in the output of layer l), gather list."""
-        n = self._config.char_layers
+        n = self._char_layers
         key = np.minimum(np.maximum(word_len, 1), hip.MAX_CONV_GROUPS - 1)
         order = np.argsort(key, kind="stable")
         ks, starts, counts = np.unique(key[order], return_index=True, return_counts=True)
@@ -261,24 +262,15 @@ class _HipNet:
         if pair.lo is not None:
             pair.lo[:numel].zero_()
 
-    def _trunk(self, bt, final, final_w, lang_dsts, tap=None, tap_w=0, ext_b=None, ext_b_w=0, ext_b_col=0,
-               want_aux=False):
-        """Character CNN (WordGram, modules.py:450-484), external-embedding MLPs, word-level input
-        assembly and the word-level gated CNN (parser.py:130-176 / tagger.py:102-148).
-        final: Pair [B*T, final_w] that receives x+res of the last layer in columns [0, word_half);
-        tap: Pair that receives x+res after layer `aux_softmax_location` (parser only);
-        lang_dsts: (Pair, ld) buffers whose columns [word_half, word_half+lang) get the language
-        embedding; ext_b: optional second destination of the projected external embeddings."""
-        self._require_gpu()
-        lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
+    def _char_level(self, bt):
+        """Character CNN of WordGram (modules.py:450-481) up to the masked mean, in ragged per-length
+        layouts (`_char_layout`).  -> (pool Pair [N, pool_w], pool_w): the (x + res) masked mean per word."""
+        lib, pk, lay, buf = hip.load(), self._pk, self._lay, self._buf
         st = hip.stream_handle()
         gather = self._gather
-        lo = hip.ptr  # lo-plane pointer helper: hip.ptr(pair.lo) is None in single-pass mode
-        B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
-        BT, BL = B * T, B * L
-        ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
-
-        # ---- character level, in ragged per-length layouts (`_char_layout`)
+        lo = hip.ptr
+        N, W = bt["N"], bt["W"]
+        ch = lay.char_half
         rows = bt["char_rows"]
         l0 = pk.get("char_l0")
         nchar = len(pk["char_convs"])
@@ -311,6 +303,26 @@ class _HipNet:
         pool = buf.get("pool", N, pool_w)
         hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w,
                         word_rows=bt["word_rows"], stream=st)
+        return pool, pool_w
+
+    def _trunk(self, bt, final, final_w, lang_dsts, tap=None, tap_w=0, ext_b=None, ext_b_w=0, ext_b_col=0,
+               want_aux=False):
+        """Character CNN (WordGram, modules.py:450-484), external-embedding MLPs, word-level input
+        assembly and the word-level gated CNN (parser.py:130-176 / tagger.py:102-148).
+        final: Pair [B*T, final_w] that receives x+res of the last layer in columns [0, word_half);
+        tap: Pair that receives x+res after layer `aux_softmax_location` (parser only);
+        lang_dsts: (Pair, ld) buffers whose columns [word_half, word_half+lang) get the language
+        embedding; ext_b: optional second destination of the projected external embeddings."""
+        self._require_gpu()
+        lib, pk, lay, cfg, buf = hip.load(), self._pk, self._lay, self._config, self._buf
+        st = hip.stream_handle()
+        gather = self._gather
+        lo = hip.ptr  # lo-plane pointer helper: hip.ptr(pair.lo) is None in single-pass mode
+        B, L, T, N, W = bt["B"], bt["L"], bt["T"], bt["N"], bt["W"]
+        BT, BL = B * T, B * L
+        ch, wh, lg, P = lay.char_half, lay.word_half, lay.lang, lay.P
+
+        pool, pool_w = self._char_level(bt)
         # ---- word level input XW0 = [word | char | lang | ext] (+ root row = _r_emb for the parser)
         xw0 = buf.get("xw0", BT, lay.xw0_w)
         if N != BL:

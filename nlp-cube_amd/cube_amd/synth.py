@@ -226,6 +226,80 @@ def make_lemmatizer_state_dict(config, enc, seed=2468, out_gain=10.0, rec_gain=3
     return sd
 
 
+def make_tokenizer_state_dict(config, enc, ext_word_emb, seed=1357):
+    """Random `state_dict` for `Tokenizer(config, enc, ext_word_emb=...)` (reference: tokenizer.py:26-59;
+    its WordGram keeps the class defaults: 3 layers, lang_emb 32, modules.py:425-426)."""
+    if not isinstance(ext_word_emb, (list, tuple)):
+        ext_word_emb = [ext_word_emb]
+    ini = _Init(seed)
+    sd = {}
+    G, C = enc.num_langs, len(enc.char2int)
+    half, le, P = config.cnn_filter // 2, config.lang_emb_size, config.external_proj_size
+    ini.gated_conv_stack(sd, "_convs", config.cnn_layers, P + le + 256 + 16, half + le, config.cnn_filter)
+    sd["_wg._lang_emb.weight"] = ini.emb(G + 1, 32, 0)
+    sd["_wg._tok_emb.weight"] = ini.emb(C - 2 + 3, 256, 0)
+    sd["_wg._case_emb.weight"] = ini.emb(4, 32, 0)
+    ini.gated_conv_stack(sd, "_wg._convolutions_char", 3, 256 + 32 + 32, 256 + 32, 512)
+    ini.linear(sd, "_wg._pre_out.linear_layer", 256, 256)
+    sd["_lang_emb.weight"] = ini.emb(G + 1, le, 0)
+    sd["_spa_emb.weight"] = ini.emb(3, 16, 0)
+    ini.linear(sd, "_output.linear_layer", 5, half + le)
+    for i, e in enumerate(ext_word_emb):
+        ini.linear(sd, "_ext_proj.%d._h1.linear_layer" % i, 500, e)
+        ini.linear(sd, "_ext_proj.%d._h2.linear_layer" % i, P, 500)
+    return sd
+
+
+def make_token_batch(enc, sent_pieces, ext_word_emb, seed=0, lang_ids=None):
+    """A batch in the format `TokenCollateHF.collate_fn` hands to `Tokenizer.forward`
+    (utils_tokenizer.py:394-576), built from synthetic sub-word pieces instead of a HuggingFace
+    tokenizer + LM (not available offline): `sent_pieces` = pieces per example; x_input = K tensors
+    [B, T, E_k] ~ N(0,1) with zero rows at the pads (the LM output at pad positions is replaced by
+    zeros here; the reference feeds whatever the LM produced for its PAD id)."""
+    rng = np.random.default_rng(seed)
+    chars = [c for c, i in enc.char2int.items() if i >= 3]
+    B, T = len(sent_pieces), int(max(sent_pieces))
+    words, langs = [], []
+    x_lang = np.zeros(B, dtype=np.int64)
+    for b, n in enumerate(sent_pieces):
+        lang = int(rng.integers(enc.num_langs)) if lang_ids is None else int(lang_ids[b])
+        x_lang[b] = lang + 1
+        for _ in range(int(n)):
+            wl = int(np.clip(1 + rng.poisson(3), 1, 12))
+            w = "".join(rng.choice(chars, wl))
+            if rng.random() < 0.2:
+                w = w[0].upper() + w[1:]
+            words.append(w)
+            langs.append(lang)   # the reference passes the raw language id here, not id + 1 (:427)
+    N, W = len(words), max(len(w) for w in words)
+    x_char = np.zeros((N, W), dtype=np.int64)
+    x_case = np.zeros((N, W), dtype=np.int64)
+    x_mask = np.zeros((N, W), dtype=np.float64)
+    for i, w in enumerate(words):
+        for p, ch in enumerate(w):
+            x_mask[i, p] = 1
+            x_case[i, p] = 1 if ch.lower() == ch.upper() else (2 if ch.lower() != ch else 3)
+            x_char[i, p] = enc.char2int.get(ch.lower(), enc.char2int["<UNK>"])
+    spa = np.zeros((B, T), dtype=np.int64)
+    x_input = []
+    valid = np.arange(T)[None, :] < np.asarray(sent_pieces)[:, None]
+    spa[valid] = rng.integers(1, 3, size=int(valid.sum()))
+    for e in ext_word_emb:
+        x = rng.standard_normal((B, T, e)).astype(np.float32)
+        x[~valid] = 0
+        x_input.append(torch.from_numpy(x))
+    text, pos = [], 0
+    for n in sent_pieces:
+        text.append(words[pos:pos + int(n)])
+        pos += int(n)
+    return {"x_input": x_input, "x_input_spa": torch.from_numpy(spa), "x_word_char": torch.from_numpy(x_char),
+            "x_word_case": torch.from_numpy(x_case), "x_word_masks": torch.from_numpy(x_mask),
+            "x_word_len": torch.tensor([len(w) for w in words], dtype=torch.long),
+            "x_word_lang": torch.tensor(langs, dtype=torch.long), "x_text": text, "x_lang": torch.from_numpy(x_lang),
+            "y_offset": torch.zeros(B, dtype=torch.long), "y_len": torch.tensor([int(n) for n in sent_pieces]),
+            "x_sent_len": torch.tensor([int(n) for n in sent_pieces], dtype=torch.long)}
+
+
 # ------------------------------------------------------------------------------------------
 # corpora
 # ------------------------------------------------------------------------------------------

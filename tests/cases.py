@@ -4,7 +4,7 @@ inputs from the same seeds and compare with the stored reference outputs)."""
 import numpy as np
 
 from cube_amd import synth
-from cube_amd.io_utils.config import ParserConfig, TaggerConfig, LemmatizerConfig
+from cube_amd.io_utils.config import ParserConfig, TaggerConfig, LemmatizerConfig, TokenizerConfig
 
 # tiny dims: every stage exercised, weights small, reference runs in milliseconds
 TINY = dict(name="tiny", seed=11, ext=(12, 8), dims=dict(char_emb_size=16, char_filter_size=32, char_layers=3,
@@ -64,6 +64,25 @@ def lemmatizer_model(case):
     enc = synth.make_encodings(**case["vocab"])
     sd = synth.make_lemmatizer_state_dict(cfg, enc, seed=case["seed"])
     return cfg, enc, sd
+
+
+TOKENIZER = dict(name="tokenizer", seed=1357, ext=(48, 48, 48), dims={}, vocab={})
+TOKENIZER_SMALL = dict(name="tokenizer_small", seed=1358, ext=(12,), dims=dict(cnn_filter=64, lang_emb_size=8, cnn_layers=3,
+                       external_proj_size=3), vocab=TINY["vocab"])
+_TOKEN_BATCHES = {"ragged": ([9, 2, 14, 1, 5, 7], 201), "equal": ([11] * 5, 202), "one": ([1], 203),
+                  "long": ([300, 120, 257], 204)}
+
+
+def tokenizer_model(case):
+    cfg = _cfg(TokenizerConfig, case["dims"])
+    enc = synth.make_encodings(**case["vocab"])
+    sd = synth.make_tokenizer_state_dict(cfg, enc, list(case["ext"]), seed=case["seed"])
+    return cfg, enc, sd
+
+
+def token_batch(case, enc, key):
+    pieces, seed = _TOKEN_BATCHES[key]
+    return synth.make_token_batch(enc, pieces, case["ext"], seed=seed)
 
 
 def lemma_document(enc, key, max_word_len=16):

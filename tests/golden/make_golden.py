@@ -218,6 +218,29 @@ def g8_tagger_process():
             print("g8", tag, bs)
 
 
+def g10_tokenizer():
+    """Tokenizer.forward logits on synthetic sub-word batches (the HF collate is not available offline)."""
+    from cube.networks.tokenizer import Tokenizer
+    from cube.io_utils.config import TokenizerConfig as RefTokenizerConfig
+    save = {}
+    for case, tag in ((cases.TOKENIZER_SMALL, "small"), (cases.TOKENIZER, "full")):
+        cfg, enc, sd = cases.tokenizer_model(case)
+        rc = RefTokenizerConfig()
+        for k, v in cfg.__dict__.items():
+            if not k.startswith("_"):
+                setattr(rc, k, v)
+        m = Tokenizer(rc, ref_encodings(enc), language_codes=None, ext_word_emb=list(case["ext"]))
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        for key in ("ragged", "equal", "one", "long"):
+            X = cases.token_batch(case, enc, key)
+            with torch.no_grad():
+                y = m.forward(X)
+            save["%s/%s" % (tag, key)] = y.numpy().astype(np.float32)
+            print("g10", tag, key, tuple(y.shape))
+    np.savez_compressed(os.path.join(HERE, "g10_tokenizer.npz"), **save)
+
+
 def build_ref_lemmatizer(case):
     cfg, enc, sd = cases.lemmatizer_model(case)
     rc = _LEMMA["LemmatizerConfig"]()
@@ -265,7 +288,7 @@ def g9_lemmatizer():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_collate()
     if "g2" in which:
@@ -282,3 +305,5 @@ if __name__ == "__main__":
         g8_tagger_process()
     if "g9" in which:
         g9_lemmatizer()
+    if "g10" in which:
+        g10_tokenizer()

@@ -120,15 +120,16 @@ def test_gemm_gate_epilogue_and_rowmap(dev, split, M, seq, Kc, half):
     def obuf(cols):
         return hip.Pair(torch.zeros((M, cols), dtype=torch.bfloat16, device=dev),
                         torch.zeros((M, cols), dtype=torch.bfloat16, device=dev) if split else None)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         res = res0.clone().to(dev)
         out0, out1 = obuf(half + 8), obuf(half)
         hip.gemm(Ad, Kc, M, pk["Kc"], Wd, pk["N"], pk["bias"].to(dev), hip.EPI_GATE, out0=out0, ldo0=half + 8, col0=8,
                  taps=5, seq_len=seq, n_valid=half, res=res, ld_res=half, res_mode=mode, out1=out1, ldo1=half, col1=0)
         torch.cuda.synchronize()
-        exp_res = gate if mode == 0 else (res0 + gate if mode == 1 else res0 + 2 * gate)
+        exp_res = gate if mode == 0 else (res0 + 2 * gate if mode == 2 else res0 + gate)
         np.testing.assert_allclose(res.cpu().numpy(), exp_res.numpy(), rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(out0.float()[:, 8:].cpu().numpy(), gate.numpy(), rtol=otol, atol=otol)
+        np.testing.assert_allclose(out0.float()[:, 8:].cpu().numpy(), (exp_res if mode == 3 else gate).numpy(),
+                                   rtol=otol, atol=otol * (4 if mode == 3 else 1))
         np.testing.assert_allclose(out1.float().cpu().numpy(), (exp_res + gate).numpy(), rtol=otol, atol=otol)
     # rowmap scatter (unpack fused into the epilogue)
     Wl = torch.randn((128, Kc), generator=g) / 8
