@@ -507,3 +507,57 @@ def pack_lemmatizer(sd, cfg, n_chars):
     row[0, lay.xd_emb:lay.xd_emb + ce] = sf[n_ctx:n_ctx + ce]
     pk["start"] = _bf16(row)
     return pk, lay
+
+
+# ------------------------------------------------------------------------------------------
+# tokenizer (reference: cube/networks/tokenizer.py:26-59)
+# ------------------------------------------------------------------------------------------
+class TokenizerLayout:
+    """XW0 [ext | char 256 | spa 16] (language: bias table); FIN [x+res | lang] (input of `_output`)."""
+
+    def __init__(self, cfg):
+        # WordGram keeps its class defaults (modules.py:425-426)
+        self.char_emb, self.case_emb, self.lang, self.char_half = 256, 32, 32, 256
+        self.xc0_w = p32(self.char_emb + self.case_emb)
+        self.xc_w = p32(self.char_half)
+        self.P, self.word_half, self.word_lang, self.spa = cfg.external_proj_size, cfg.cnn_filter // 2, cfg.lang_emb_size, 16
+        self.xw0_char = p8(self.P)
+        self.xw0_spa = self.xw0_char + self.char_half
+        self.xw0_w = p32(self.xw0_spa + self.spa)
+        self.xw_w = p32(self.word_half)
+        self.fin_w = p32(self.word_half + p8(self.word_lang))
+
+    def xw0_perm(self):
+        """XW0 column -> input channel of the first conv ([ext, char, spa, lang], tokenizer.py:100-102)."""
+        perm = -np.ones(self.xw0_w, dtype=np.int64)
+        perm[:self.P] = np.arange(self.P)
+        perm[self.xw0_char:self.xw0_char + self.char_half] = self.P + np.arange(self.char_half)
+        perm[self.xw0_spa:self.xw0_spa + self.spa] = self.P + self.char_half + np.arange(self.spa)
+        return perm
+
+
+def pack_tokenizer(sd, cfg, enc_sizes, ext_dims):
+    lay = TokenizerLayout(cfg)
+    pk = pack_wordgram(sd, "_wg", 3, lay.char_emb, lay.case_emb, lay.lang, lay.char_half)
+    pk["ext"] = []
+    for i, e in enumerate(ext_dims):
+        h1 = pack_linear(sd["_ext_proj.%d._h1.linear_layer.weight" % i], sd["_ext_proj.%d._h1.linear_layer.bias" % i])
+        hid = sd["_ext_proj.%d._h2.linear_layer.weight" % i].shape[1]
+        h2 = pack_linear(sd["_ext_proj.%d._h2.linear_layer.weight" % i], sd["_ext_proj.%d._h2.linear_layer.bias" % i],
+                         in_perm=np.concatenate([np.arange(hid), -np.ones(h1["N"] - hid, dtype=np.int64)]))
+        pk["ext"].append(dict(h1=h1, h2=h2, E=e, Epad=p32(e)))
+    pk["spa_emb"] = pack_table(sd["_spa_emb.weight"])
+    pk["lang_emb"] = pack_table(sd["_lang_emb.weight"], p8(lay.word_lang))
+    lang_tab = sd["_lang_emb.weight"].float()
+    first = lay.P + lay.char_half + lay.spa
+    pk["word_convs"] = []
+    for l in range(cfg.cnn_layers):
+        if l == 0:
+            pk["word_convs"].append(pack_gated_conv(sd, "_convs.0", lay.xw0_perm(), bcast=(first + np.arange(lay.word_lang), lang_tab)))
+        else:
+            pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, np.arange(lay.word_half),
+                                                    bcast=(lay.word_half + np.arange(lay.word_lang), lang_tab)))
+    perm = -np.ones(lay.fin_w, dtype=np.int64)
+    perm[:lay.word_half + lay.word_lang] = np.arange(lay.word_half + lay.word_lang)
+    pk["output"] = pack_linear(sd["_output.linear_layer.weight"], sd["_output.linear_layer.bias"], in_perm=perm)
+    return pk, lay

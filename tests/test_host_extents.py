@@ -110,3 +110,17 @@ def test_lemmatizer_host_extents(case, precision, monkeypatch):
         assert oc.shape == (n, 11) and steps == 11 and logits.shape[0] == 11
     kinds = {c[0] for c in lib.calls}
     assert {"gemm", "gather", "lemma_attend", "lstm_cell"} <= kinds
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", [cases.TOKENIZER_SMALL, cases.TOKENIZER], ids=["small", "full"])
+def test_tokenizer_host_extents(case, precision, monkeypatch):
+    """Every pointer of Tokenizer.forward covers what its kernel touches (ragged, equal, one piece, long)."""
+    from cube_amd.networks.tokenizer import Tokenizer
+    cfg, enc, sd = cases.tokenizer_model(case)
+    m, lib = abi_trace.dry_net(Tokenizer, cfg, enc, sd, case["ext"], precision, monkeypatch)
+    for key in ("ragged", "equal", "one", "long"):
+        X = cases.token_batch(case, enc, key)
+        y = m.forward(X)
+        assert tuple(y.shape) == (len(X["x_sent_len"]), X["x_input"][0].shape[1], 5)
+    assert {"gemm", "gather", "masked_mean", "ext_finish"} <= {c[0] for c in lib.calls}
