@@ -5,8 +5,12 @@ Mirror of the reference API (cube/api.py:39-128, 183-211): `Cube().load(lang, de
 tokenization is implemented here: `lm_helper.apply(doc)` followed by
 `Parser.process(doc, collate, num_workers=0)` and `Lemmatizer.process(doc, collate,
 num_workers=0)` (api.py:124-126; the lemmatizer is loaded when its `-trf-lemmatizer.*` files are in
-the model directory, otherwise lemmas are left untouched).  Raw-string input needs the tokenizer
-stage, which is out of scope, so a `str` raises NotImplementedError.  Model download (api.py:150-180) needs the network and is not done:
+the model directory, otherwise lemmas are left untouched).  Raw-string input runs the tokenizer
+network (api.py:52-80,118) when the caller supplies the sub-word collate it needs
+(`tokenizer_collate=`: the reference's `TokenCollateHF` / `TokenCollateFTLanguasito` wrap a
+HuggingFace / fastText model that this package does not re-implement); without one a `str` raises
+NotImplementedError.  The compound-word expander (`-trf-cwe`, api.py:41-50,119-120) is not built.
+Model download (api.py:150-180) needs the network and is not done:
 the model directory `~/.nlpcube/3.0/<lang>` must already exist.
 """
 import os
@@ -15,19 +19,20 @@ from typing import Optional, Union
 
 import yaml
 
-from cube_amd.io_utils.config import LemmatizerConfig, ParserConfig
+from cube_amd.io_utils.config import LemmatizerConfig, ParserConfig, TokenizerConfig
 from cube_amd.io_utils.encodings import Encodings
 from cube_amd.io_utils.objects import Document
 from cube_amd.networks.lemmatizer import Lemmatizer, Word2TargetCollate
 from cube_amd.networks.lm import LMHelperDummy, LMHelperPrecomputed
 from cube_amd.networks.parser import Parser
+from cube_amd.networks.tokenizer import Tokenizer
 from cube_amd.networks.utils import MorphoCollate
 
 
 class CubeObj:
     """reference: cube/api.py:39-128 (parser-tagger part :91-106, dispatch :108-128)."""
 
-    def __init__(self, model_base: str, device: str = "cpu", lang: str = None, lm_helper=None):
+    def __init__(self, model_base: str, device: str = "cpu", lang: str = None, lm_helper=None, tokenizer_collate=None):
         path = "{0}-trf-tokenizer".format(model_base)
         with open("{0}.yaml".format(path)) as f:
             g_conf = yaml.safe_load(f)
@@ -36,6 +41,17 @@ class CubeObj:
             self._lang2id[lng] = len(self._lang2id)
         self._default_lang_id = self._lang2id[g_conf["language_map"][lang]]
         self._default_lang = lang
+        # tokenizer (api.py:60-80), only with a caller-supplied sub-word collate
+        self._tokenizer = None
+        if tokenizer_collate is not None:
+            config = TokenizerConfig(filename="{0}.config".format(path))
+            encodings = Encodings()
+            encodings.load("{0}.encodings".format(path))
+            self._tokenizer_collate = tokenizer_collate
+            self._tokenizer = Tokenizer(config, encodings, language_codes=g_conf["language_codes"],
+                                        ext_word_emb=tokenizer_collate.get_embeddings_size())
+            self._tokenizer.load("{0}.best".format(path))
+            self._tokenizer.to(device)
         # lemmatizer (api.py:82-90)
         self._lemmatizer = None
         path = "{0}-trf-lemmatizer".format(model_base)
@@ -75,10 +91,12 @@ class CubeObj:
                                 format(" ".join([k for k in self._lang2id])))
             lang_id = self._lang2id[flavour]
         if isinstance(text, str):
-            raise NotImplementedError("raw text needs the tokenizer stage, which runs before the accelerated "
-                                      "path; pass a tokenised Document")
-        doc = text  # a Document keeps its own sentence.lang_id (api.py:121-122)
-        del lang_id
+            if self._tokenizer is None:
+                raise NotImplementedError("raw text needs the tokenizer stage and its sub-word collate: construct "
+                                          "CubeObj(..., tokenizer_collate=...) or pass a tokenised Document")
+            doc = self._tokenizer.process(text, self._tokenizer_collate, lang_id=lang_id, num_workers=0)
+        else:
+            doc = text  # a Document keeps its own sentence.lang_id (api.py:121-122)
         self._lm_helper.apply(doc)
         self._parser.process(doc, self._parser_collate, num_workers=0)
         if self._lemmatizer is not None:
@@ -86,12 +104,13 @@ class CubeObj:
         return doc
 
 
-def _load(lang: str, device: Optional[str] = "cpu", lm_helper=None) -> CubeObj:
+def _load(lang: str, device: Optional[str] = "cpu", lm_helper=None, tokenizer_collate=None) -> CubeObj:
     try:
         lang_path = os.path.join(str(Path.home()), ".nlpcube", "3.0", lang)
         if not os.path.exists(lang_path):
             raise FileNotFoundError(lang_path)
-        return CubeObj("{0}/{1}".format(lang_path, lang), device=device, lang=lang, lm_helper=lm_helper)
+        return CubeObj("{0}/{1}".format(lang_path, lang), device=device, lang=lang, lm_helper=lm_helper,
+                       tokenizer_collate=tokenizer_collate)
     except Exception:
         # one generic exception for every load failure, like the reference (api.py:193-200)
         raise Exception("There was a problem retrieving this language: model files for '%s' are not available "
@@ -104,8 +123,8 @@ class Cube:
     def __init__(self, verbose=False):
         self._instance = None
 
-    def load(self, lang: str, device: Optional[str] = "cpu", lm_helper=None):
-        self._instance = _load(lang, device, lm_helper=lm_helper)
+    def load(self, lang: str, device: Optional[str] = "cpu", lm_helper=None, tokenizer_collate=None):
+        self._instance = _load(lang, device, lm_helper=lm_helper, tokenizer_collate=tokenizer_collate)
 
     def __call__(self, text: Union[str, Document], flavour: Optional[str] = None):
         return self._instance(text, flavour=flavour)
