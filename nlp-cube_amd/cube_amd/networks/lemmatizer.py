@@ -372,17 +372,31 @@ class Lemmatizer:
                     w.lemma = keys[(w.word, w.upos, sent.lang_id)]
         return doc
 
-    def process(self, doc, collate, batch_size=4, num_workers=4):
-        """reference: lemmatizer.py:185-231.  `num_workers` is accepted and ignored."""
+    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_words=8192):
+        """reference: lemmatizer.py:185-231.  `num_workers` is accepted and ignored.
+        merge (no counterpart in the reference, results unchanged): the reference's in-order batches of
+        `batch_size` words whose longest word has the same length (same S, hence the same pad positions
+        for every word in them) run together as one device batch of up to `max_words` words; words do not
+        interact otherwise (`sharding.merged_reference_batches`)."""
         self._require_gpu()
         dataset = LemmaDataset(doc, for_training=False)
-        all_lemmas = []
-        for s in range(0, len(dataset), batch_size):
-            items = [dataset[i] for i in range(s, min(s + batch_size, len(dataset)))]
+        n = len(dataset)
+        starts = list(range(0, n, batch_size))
+        if merge and len(starts) > 1:
+            from cube_amd.sharding import merged_reference_batches
+            keys = [max(len(dataset[i]["word"]) for i in range(a, min(a + batch_size, n))) for a in starts]
+            groups = merged_reference_batches(keys, batch_size, max_words)
+            device_batches = [[i for r in g for i in range(starts[r], min(starts[r] + batch_size, n))] for g in groups]
+        else:
+            device_batches = [list(range(a, min(a + batch_size, n))) for a in starts]
+        all_lemmas = [None] * n
+        for ids in device_batches:
+            items = [dataset[i] for i in ids]
             batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
             batch.pop("y_char", None)
             batch.pop("y_case", None)
-            all_lemmas.extend(self._strings(*self.decode_batch(batch)))
+            for i, lemma in zip(ids, self._strings(*self.decode_batch(batch))):
+                all_lemmas[i] = lemma
         i = 0
         for sent in doc.sentences:
             for w in sent.words:

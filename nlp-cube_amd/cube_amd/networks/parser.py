@@ -637,8 +637,9 @@ class Parser(_HipNet):
     def _write_back(self, batch, start, res, status):
         """parser.py:432-446: ids -> strings, into the Document."""
         if (status != 0).any():
+            ids = np.asarray(start) + np.arange(len(status)) if np.ndim(start) == 0 else np.asarray(start)
             raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
-                                 % (start + np.where(status != 0)[0]).tolist())
+                                 % ids[status != 0].tolist())
         enc = self._encodings
         tabs = getattr(self, "_str_tabs", None)
         if tabs is None:  # id -> string tables as object arrays: one fancy-index per batch instead of a list lookup per word
@@ -680,13 +681,30 @@ class Parser(_HipNet):
         self._run_batches(([sents[i] for i in idx], int(idx[0])) for idx in groups)
         return doc
 
-    def process(self, doc, collate, batch_size=4, num_workers=4):
+    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=8192):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
         head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
-        two deep (featurisation and write-back of neighbours overlap the GPU)."""
+        two deep (featurisation and write-back of neighbours overlap the GPU).
+        merge (no counterpart in the reference, results unchanged): reference batches with the same
+        padding geometry (longest sentence, longest word) run together as one device batch of up to
+        `max_tokens` padded tokens — every sentence still sees exactly the padding of its own
+        reference batch, and sentences do not interact otherwise (`sharding.merged_reference_batches`)."""
         self.eval()
         self._require_gpu()
         self._collate = collate
         sents = doc.sentences
-        self._run_batches((sents[start:start + batch_size], start) for start in range(0, len(sents), batch_size))
+        starts = list(range(0, len(sents), batch_size))
+        if not merge or len(starts) < 2:
+            self._run_batches((sents[start:start + batch_size], start) for start in starts)
+            return doc
+        from cube_amd.sharding import merged_reference_batches
+        keys = [(max(len(s.words) for s in sents[a:a + batch_size]),
+                 max((len(w.word) for s in sents[a:a + batch_size] for w in s.words), default=0)) for a in starts]
+        groups = merged_reference_batches(keys, batch_size, lambda k: min(1024, max_tokens // (k[0] + 1)))
+
+        def batches():
+            for g in groups:
+                ids = [i for r in g for i in range(starts[r], min(starts[r] + batch_size, len(sents)))]
+                yield [sents[i] for i in ids], np.asarray(ids)
+        self._run_batches(batches())
         return doc

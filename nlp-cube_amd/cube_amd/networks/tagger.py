@@ -59,10 +59,13 @@ class Tagger(_HipNet):
         r["packed"] = packed
         return r
 
-    def process(self, doc, collate, upos=True, xpos=True, attrs=True, batch_size=32, num_workers=4):
+    def process(self, doc, collate, upos=True, xpos=True, attrs=True, batch_size=32, num_workers=4, merge=True,
+                max_tokens=8192):
         """reference: tagger.py:288-329 — in-order batches; fills upos / xpos / attrs of every word.
         The ids of a batch come back through pinned memory by an asynchronous copy, so the host
-        prepares batch i+1 and writes batch i-1 back while the GPU works on batch i."""
+        prepares batch i+1 and writes batch i-1 back while the GPU works on batch i.
+        merge: reference batches with the same padding geometry run together as one device batch, results
+        unchanged (see Parser.process / sharding.merged_reference_batches)."""
         self.eval()
         if not (upos or xpos or attrs):
             raise Exception("To perform tagging at least one of 'upos', 'xpos' or 'attrs' must be set to True.")
@@ -85,9 +88,17 @@ class Tagger(_HipNet):
                         w.attrs = a
 
         sents = doc.sentences
+        starts = list(range(0, len(sents), batch_size))
+        if merge and len(starts) > 1:
+            from cube_amd.sharding import merged_reference_batches
+            keys = [(max(len(s.words) for s in sents[a:a + batch_size]),
+                     max((len(w.word) for s in sents[a:a + batch_size] for w in s.words), default=0)) for a in starts]
+            groups = merged_reference_batches(keys, batch_size, lambda k: min(1024, max_tokens // max(k[0], 1)))
+            device_batches = [[s for r in g for s in sents[starts[r]:starts[r] + batch_size]] for g in groups]
+        else:
+            device_batches = [sents[a:a + batch_size] for a in starts]
         pending = None
-        for k, start in enumerate(range(0, len(sents), batch_size)):
-            batch = sents[start:start + batch_size]
+        for k, batch in enumerate(device_batches):
             X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
             X.pop("y_upos", None)
             packed = self.tag_batch(X)["packed"]

@@ -35,6 +35,27 @@ def bucketed_batches(sent_lens, max_tokens=8192, max_sentences=1024):
     return out
 
 
+def merged_reference_batches(keys, batch_size, cap):
+    """The reference's in-order batches (`batch_size` consecutive items each), merged into device
+    batches WITHOUT changing any result.  What an item's result depends on in its reference batch is
+    only the padding geometry of that batch (`keys[i]` = the geometry of reference batch i: longest
+    sentence and longest word for the parser / tagger, longest word for the lemmatizer): items never
+    interact otherwise.  Reference batches with equal geometry are therefore concatenated, up to `cap`
+    items per device batch (always whole reference batches), and every item sees exactly the padding
+    it would have seen alone with its own batch.
+    keys: one hashable per reference batch; cap: items per device batch, an int or a function of the
+    key -> list of lists of reference-batch indices (buckets in order of first appearance)."""
+    buckets = {}
+    for i, k in enumerate(keys):
+        buckets.setdefault(k, []).append(i)
+    out = []
+    for k, idx in buckets.items():
+        per = max(1, (cap(k) if callable(cap) else cap) // max(batch_size, 1))
+        for s in range(0, len(idx), per):
+            out.append(idx[s:s + per])
+    return out
+
+
 class _Slice:
     """A view of a Document holding only sentences[lo:hi] (same Sentence objects)."""
 

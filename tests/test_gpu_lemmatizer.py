@@ -246,3 +246,19 @@ def test_process_bucketed_is_batch_independent(dev):
                 continue
             X = col.collate_fn([{"word": w.word, "upos": w.upos, "lang_id": sent.lang_id, "target": ""}], targets=False)
             assert m._strings(*m.decode_batch(X))[0] == w.lemma
+
+
+def test_merged_reference_batches_do_not_change_lemmas(dev):
+    """Lemmatizer.process with merge=True == merge=False at the reference's default batch size of 4 words."""
+    from cube_amd.networks.lemmatizer import Word2TargetCollate
+    m, cfg, enc, sd = _model("full", dev)
+    col = Word2TargetCollate(enc)
+    a = cases.lemma_document(enc, "g6", max_word_len=4)
+    b = cases.lemma_document(enc, "g6", max_word_len=4)
+    m.max_steps = 24   # bound the test: a random decoder runs into the 20*S failsafe otherwise
+    try:
+        m.process(a, col, batch_size=4, merge=True)
+        m.process(b, col, batch_size=4, merge=False)
+    finally:
+        m.max_steps = None
+    assert [w.lemma for s in a.sentences for w in s.words] == [w.lemma for s in b.sentences for w in s.words]

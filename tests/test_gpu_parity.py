@@ -618,3 +618,29 @@ def test_cube_api_loads_model_files_and_parses(dev, tmp_path):
         cube(a, flavour="xx_unknown")
     with pytest.raises(NotImplementedError):
         cube("raw text needs the tokenizer")
+
+
+def test_merged_reference_batches_do_not_change_results(dev):
+    """Parser.process / Tagger.process with merge=True (reference batches of equal padding geometry run as
+    one device batch) give bit-identical documents to merge=False (one launch sequence per reference
+    batch), at the reference's default batch sizes."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    from cube_amd.networks.tagger import Tagger
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 7, size=203)
+    docs = [synth.make_document(enc, lens, seed=77, ext_word_emb=case["ext"], max_word_len=5) for _ in range(4)]
+    col = MorphoCollate(enc)
+    p.process(docs[0], col, batch_size=4, merge=True)
+    p.process(docs[1], col, batch_size=4, merge=False)
+    assert str(docs[0]) == str(docs[1])
+    tcfg, tenc, tsd = cases.tagger_model(cases.TINY_TAGGER)
+    t = Tagger(tcfg, tenc, ext_word_emb=list(cases.TINY_TAGGER["ext"]))
+    t.load_state_dict(tsd)
+    t.to(dev)
+    tdocs = [synth.make_document(tenc, lens, seed=78, ext_word_emb=cases.TINY_TAGGER["ext"], max_word_len=5) for _ in range(2)]
+    t.process(tdocs[0], MorphoCollate(tenc), batch_size=8, merge=True)
+    t.process(tdocs[1], MorphoCollate(tenc), batch_size=8, merge=False)
+    assert str(tdocs[0]) == str(tdocs[1])

@@ -87,3 +87,18 @@ def test_bucketed_batches_cover_every_sentence_within_the_token_budget():
         assert (np.diff(lens[g]) >= 0).all()
     assert bucketed_batches([], 8192) == []
     assert [g.tolist() for g in bucketed_batches([9000, 2], 8192)] == [[1], [0]]  # an over-long sentence still gets a batch
+
+
+def test_merged_reference_batches_keep_whole_batches_of_one_geometry():
+    import numpy as np
+    from cube_amd.sharding import merged_reference_batches
+    rng = np.random.default_rng(4)
+    keys = [(int(a), int(b)) for a, b in zip(rng.integers(3, 9, size=300), rng.integers(8, 11, size=300))]
+    groups = merged_reference_batches(keys, 4, lambda k: 64 // k[0] * 4)
+    assert sorted(i for g in groups for i in g) == list(range(300))          # every reference batch exactly once
+    for g in groups:
+        assert len({keys[i] for i in g}) == 1                                # one padding geometry per device batch
+        assert g == sorted(g)                                                # reference order inside it
+        assert len(g) * 4 <= max(4, 64 // keys[g[0]][0] * 4)                 # the cap, in items
+    assert merged_reference_batches([], 4, 100) == []
+    assert merged_reference_batches(["a", "b", "a"], 4, 1) == [[0], [2], [1]]  # cap below one batch: never split a batch
