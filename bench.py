@@ -75,20 +75,20 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300
 def run_steps(p, batches, n):
     """n steps, each: device-resident batch -> five int32 arrays on the host (`Parser.submit` /
     `collect`: the latency-bound second phase of a step overlaps the first phase of the next)."""
-    pending = None
     out = None
     if os.environ.get("CUBE_BENCH_SERIAL") == "1":  # profiling aid: one stream, kernels never overlap
         for i in range(n):
             r = p.decode_batch_prepared(batches[i % len(batches)])
             out = r["packed"].cpu()
         return out
+    from collections import deque
+    inflight = deque()
     for i in range(n):
-        t = p.submit(batches[i % len(batches)])
-        if pending is not None:
-            out = p.collect(pending)
-        pending = t
-    if pending is not None:
-        out = p.collect(pending)
+        inflight.append(p.submit(batches[i % len(batches)]))
+        if len(inflight) == p.N_SLOTS:  # host runs N_SLOTS - 1 batches ahead of the one it waits for
+            out = p.collect(inflight.popleft())
+    while inflight:
+        out = p.collect(inflight.popleft())
     return out
 
 

@@ -478,7 +478,7 @@ class Parser(_HipNet):
         # ---- pre_parsing (parser.py:202-203) and the arc scorer (modules.py:518-533, 550-579)
         q = pk["pre_out"]
         pp_w = q["N"]
-        pp = buf.get("pp", BT, pp_w)
+        pp = buf.get("pp_%d" % slot, BT, pp_w)  # per slot: read by the decode stage while the next batch is encoded
         hip.gemm(src, src_ld, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pp, ldo0=pp_w,
                  n_valid=q["n_valid"], stream=st)
         q = pk["head_in"]
@@ -489,8 +489,8 @@ class Parser(_HipNet):
         q = pk["head_bilin"]
         u = buf.get("u", BT, Dh)
         hip.gemm(ha, 2 * Dh, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
-        arc_logits = buf.get("arc_logits", B * L, T, torch.float32)[:B * L * T].view(B, L, T)
-        arc_probs = buf.get("arc_probs", B * L, T, torch.float32)[:B * L * T].view(B, L, T)
+        arc_logits = buf.get("arc_logits_%d" % slot, B * L, T, torch.float32)[:B * L * T].view(B, L, T)
+        arc_probs = buf.get("arc_probs_%d" % slot, B * L, T, torch.float32)[:B * L * T].view(B, L, T)
         hip.check(lib.cube_biaffine_arc(u.hi.data_ptr(), lo(u.lo), Dh, ha.hi.data_ptr(), lo(ha.lo), 2 * Dh, Dh, Dh, B, T,
                                         arc_logits.data_ptr(), arc_probs.data_ptr(), st), "cube_biaffine_arc")
         fr.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w)
@@ -583,21 +583,25 @@ class Parser(_HipNet):
         return self._decode(bt, self._encode(bt))
 
     # ---- pipelined execution: GEMM-heavy phase of batch i+1 overlaps the latency-bound phase of i ----
+    N_SLOTS = 3
+
     def submit(self, bt):
-        """Enqueue one prepared batch.  Phase 1 (char/word CNNs, tag heads: fills all CUs) runs on
-        one HIP stream, phase 2 (persistent BiLSTM, arc scorer, MST, labels: few workgroups, serial
-        steps) on a second one, so phase 2 of a batch hides under phase 1 of the next.  Returns a
-        ticket for `collect`.  At most two batches may be in flight."""
+        """Enqueue one prepared batch on three HIP streams, one per stage: (1) char/word CNNs and tag
+        heads (GEMMs that fill all CUs), (2) BiLSTM, pre_parsing and the arc scorer (a few persistent
+        workgroups, serial steps), (3) MST decode, label scorer and the D->H copy of the results.  The
+        stages of one batch run in order (events); the latency-bound stages 2 and 3 of earlier batches
+        run under stage 1 of later ones.  Returns a ticket for `collect`.  At most `N_SLOTS` batches
+        may be in flight (submitted, not collected)."""
         self._require_gpu()
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
-            self._slot_free = [None, None]
-            self._host_res = [None, None]
+            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
+            self._slot_free = [None] * self.N_SLOTS
+            self._host_res = [None] * self.N_SLOTS
             self._n_submitted = 0
             self._buf.streams = self._streams
-        slot = self._n_submitted % 2
+        slot = self._n_submitted % self.N_SLOTS
         self._n_submitted += 1
-        s1, s2 = self._streams
+        s1, s2, s3 = self._streams
         cur = torch.cuda.current_stream()
         B, L = bt["B"], bt["L"]
         with torch.cuda.stream(s1):
@@ -609,7 +613,12 @@ class Parser(_HipNet):
             ev_front.record(s1)
         with torch.cuda.stream(s2):
             s2.wait_event(ev_front)
-            r = self._decode(bt, self._back(bt, fr, slot), slot)
+            r = self._back(bt, fr, slot)
+            ev_back = torch.cuda.Event()
+            ev_back.record(s2)
+        with torch.cuda.stream(s3):
+            s3.wait_event(ev_back)
+            r = self._decode(bt, r, slot)
             n = 5 * B * L
             host = self._host_res[slot]
             if host is None or host.numel() < n + B:
@@ -618,11 +627,11 @@ class Parser(_HipNet):
             host[:n].view(5, B, L).copy_(r["packed"], non_blocking=True)
             host[n:n + B].copy_(r["status"], non_blocking=True)
             done = torch.cuda.Event()
-            done.record(s2)
+            done.record(s3)
             self._slot_free[slot] = done
         # the ticket keeps the batch's device inputs alive until `collect`: they were allocated on the
         # caller's stream, and freeing them earlier would let the next upload reuse their memory
-        # while the kernels of this batch (on s1 / s2) still read it
+        # while the kernels of this batch (on the stage streams) still read it
         return dict(slot=slot, done=done, B=B, L=L, bt=bt)
 
     def collect(self, ticket):
