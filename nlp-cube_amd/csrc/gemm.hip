@@ -25,15 +25,17 @@ constexpr int BK = 32;
 constexpr int ROWB = 64;  // bytes per LDS row (32 bf16); 16-byte chunks XOR-swizzled by (row>>2)&3
 
 // Tile configurations.  Big: 256x256, 8 waves (2x4), 128x64 per wave — half the LDS fill per MFMA
-// of the small one (the ds_write path, ~79 B/clk/CU, is what bounds a 128x128 tile).  Small:
-// 128x128, 4 waves (2x2), 64x64 per wave, 2 blocks/CU — for the GEMMs with few rows.
+// of the small one.  Small: 128x128, 8 waves (4x2), 32x64 per wave, 2 blocks/CU — for the GEMMs
+// with few rows.
 // SR = activation slab rows in LDS (a multiple of the 16 rows one LDS-DMA piece fills).  A tile is
 // BM OUTPUT rows; the slab holds the input rows they read (+ halo).  For plain sequences that is
 // BM + 4 rows; with ragged groups (seq_out < seq_in: the last positions of every sequence are read
 // as neighbours but produce no output) the input span of a tile is up to seq_in/seq_out longer, so
 // the slab is made as large as the 160 KiB of LDS allow and a tile takes fewer rows if it must.
 struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, SR = 352; };
-struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, SR = 176; };
+// 8 waves (4x2, 32x64 per wave): these grids are about one block per CU, and two waves per SIMD cover
+// each other's barrier / LDS latency (4 waves of 64x64 were 2..25 % slower, most on the short-K GEMMs)
+struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 4, WN = 2, SR = 176; };
 // Shorter variant of the big tile (8 waves, 96x64 per wave).  A launch of T equal tiles on 256 CUs
 // at one block per CU takes ceil(T/256) rounds: when the last round of 256-row tiles would be mostly
 // empty, more, shorter tiles finish sooner (see `launch_split`; a 128-row variant lost what it
@@ -294,12 +296,19 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
       }
       if (more) {
+        // slots q of this unit: first the next step's weight pieces, then the activation pieces of
+        // the NEXT channel chunk.  The slab buffer of chunk kc+1 is free during all taps of chunk kc,
+        // so its pieces are spread over the taps (piece a goes out on tap a % taps) instead of
+        // bunching on the last tap, where the last of them would have one MFMA group to land.
 #pragma unroll
         for (int q = u * PPU; q < (u + 1) * PPU && q < PA + PB; ++q) {
           if (q < PB) {
             ISSUE_B_PIECE(s + 1, (s + 1) & 1, q)
-          } else if (last_tap) {
-            ISSUE_A_PIECE(kc + 1, (kc + 1) & 1, q - PB)
+          } else if (kc + 1 < nkc) {
+            const int a = (q - PB) * taps + tap;  // wave-uniform
+#pragma unroll
+            for (int ai = 0; ai < PA; ++ai)
+              if (a == ai) ISSUE_A_PIECE(kc + 1, (kc + 1) & 1, ai)
           }
         }
       }
