@@ -32,22 +32,30 @@ constexpr int ROWB = 64;  // bytes per LDS row (32 bf16); 16-byte chunks XOR-swi
 // BM + 4 rows; with ragged groups (seq_out < seq_in: the last positions of every sequence are read
 // as neighbours but produce no output) the input span of a tile is up to seq_in/seq_out longer, so
 // the slab is made as large as the 160 KiB of LDS allow and a tile takes fewer rows if it must.
-struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, SR = 352; };
+struct CfgBig { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, SR = 352, NB = 2; };
 // 8 waves (4x2, 32x64 per wave): these grids are about one block per CU, and two waves per SIMD cover
 // each other's barrier / LDS latency (4 waves of 64x64 were 2..25 % slower, most on the short-K GEMMs)
-struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 4, WN = 2, SR = 176; };
+struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 4, WN = 2, SR = 176, NB = 2; };
 // Shorter variant of the big tile (8 waves, 96x64 per wave).  A launch of T equal tiles on 256 CUs
 // at one block per CU takes ceil(T/256) rounds: when the last round of 256-row tiles would be mostly
 // empty, more, shorter tiles finish sooner (see `launch_split`; a 128-row variant lost what it
 // gained to its lower per-tile efficiency and was dropped).
-struct CfgBig192 { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 272; };
+struct CfgBig192 { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 272, NB = 2; };
+// NB = weight-tile stages in LDS.  With three, the weight tile of step s+2 is in flight while step s
+// runs: the end-of-step wait is a COUNTED vmcnt (that prefetch stays outstanding across a raw
+// s_barrier) instead of the full drain a two-stage ring needs.  The third stage is paid for with a
+// shorter activation slab (ragged groups: a few rows fewer per tile).
+struct CfgBig192P { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 240, NB = 3; };
+// few-row convolutions whose 128-row tiles would be a little over one block per CU: 160-row tiles on
+// 10 waves (5x2), one block per CU, three weight stages
+struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR = 176, NB = 3; };
 
 constexpr int MAX_TAPS = 5;
 template <class C> constexpr int slab_rows() { return C::SR; }
-// LDS: [A slab x2 buffers][B tile x2 buffers][one zero row][per tile row: bias-table offset, output
+// LDS: [A slab x2 buffers][B tile x NB stages][one zero row][per tile row: bias-table offset, output
 // row, tap mask, slab row]; every operand buffer holds NP planes
 template <class C, bool SPLIT> constexpr int lds_bytes() {
-  return 2 * (SPLIT ? 2 : 1) * (slab_rows<C>() + C::BN) * ROWB + ROWB + 4 * C::BM * 4;
+  return (SPLIT ? 2 : 1) * (2 * slab_rows<C>() + C::NB * C::BN) * ROWB + ROWB + 4 * C::BM * 4;
 }
 // output rows one tile of a sequence group takes: all BM unless the input rows they read would
 // not fit the slab.  r rows touch at most (r-2)/seq_out + 2 sequences of seq_in rows each.
@@ -88,6 +96,8 @@ __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t id
   }
 }
 
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // LDS-DMA: 64 lanes x 16 bytes land at (wave-uniform) l + lane*16; the per-lane SOURCE address
@@ -114,11 +124,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   constexpr int A_PLANE = SR * ROWB, B_PLANE = BN * ROWB;
   constexpr int A_BUF = NP * A_PLANE, B_BUF = NP * B_PLANE;
   constexpr int B_BASE = 2 * A_BUF;
-  constexpr int ZERO_OFF = 2 * A_BUF + 2 * B_BUF;
+  constexpr int NB = C::NB, PD = NB - 1;                     // weight-tile stages, prefetch distance (k-steps)
+  constexpr int ZERO_OFF = 2 * A_BUF + NB * B_BUF;
   constexpr int A_PIECES = SR / 16, B_PIECES = BN / 16;      // 1-KiB DMA pieces per plane
-  constexpr int PA = (A_PIECES + NW - 1) / NW, PB = B_PIECES / NW;
+  constexpr int PA = (A_PIECES + NW - 1) / NW, PB = (B_PIECES + NW - 1) / NW;
+  constexpr bool B_EVEN = B_PIECES % NW == 0;                // every wave issues PB weight pieces per tile
   static_assert(TN == 2, "the gate epilogue pairs the two 32-column tiles of a wave");
-  static_assert(B_PIECES % NW == 0, "B pieces must divide over the waves");
+  static_assert(NB == 2 || NB == 3, "two or three weight stages");
+  static_assert(B_EVEN || B_PIECES % NW > 0, "");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     }                                                                                         \
   }
 #define ISSUE_B_PIECE(S, BUF, I)                                                              \
-  {                                                                                           \
+  if (B_EVEN || wid + NW * (I) < B_PIECES) {                                                  \
     unsigned char* l_ = smem + B_BASE + (BUF) * B_BUF + (wid + NW * (I)) * 1024;              \
     glds16(p.W + b_src[I] + (size_t)(S) * BK, l_);                                            \
     if constexpr (SPLIT) glds16(p.W_lo + b_src[I] + (size_t)(S) * BK, l_ + B_PLANE);          \
@@ -237,22 +250,28 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 
   ISSUE_A(0, 0)
   ISSUE_B(0, 0)
-  __syncthreads();
+  if constexpr (NB == 3) {
+    if (nk > 1) ISSUE_B(1, 1)
+  }
+  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int lr = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
     vmask[i] = reinterpret_cast<const uint32_t*>(smem + MASK_OFF)[lr];
     a_row[i] = reinterpret_cast<const int32_t*>(smem + AROW_OFF)[lr];  // slab row of tap 0 is a_row + 0: the slab starts half_taps rows early
   }
+  // LDS-DMA instructions this wave issues per weight tile (what a counted wait leaves in flight)
+  const bool b_full = B_EVEN || wid + NW * (PB - 1) < B_PIECES;
 
-  int kc = 0, tap = 0;
+  int kc = 0, tap = 0, stg = 0;  // stg = weight stage of step s
   for (int s = 0; s < nk; ++s) {
     const bool last_tap = (tap == taps - 1);
-    // next step's operands: one LDS-DMA piece after each MFMA group below (a piece costs the wave
+    // operands of later steps: one LDS-DMA piece after each MFMA group below (a piece costs the wave
     // 60-180 issue cycles; spread out, the queued MFMAs cover it, bunched at the top they do not)
-    const bool more = s + 1 < nk;
+    const bool pre = s + PD < nk;  // a weight tile to prefetch in this step
+    const int stg_pre = stg + PD >= NB ? stg + PD - NB : stg + PD;
     constexpr int PPU = (PA + PB + 2 * TM - 1) / (2 * TM);  // pieces per MFMA group
-    const unsigned char* bbase = smem + B_BASE + (s & 1) * B_BUF;
+    const unsigned char* bbase = smem + B_BASE + stg * B_BUF;
     // fragment reads run one (k-substep, row tile) unit ahead of the MFMAs that consume them
     int aoff[TM], alo[TM];  // LDS byte offsets of this lane's A fragment (k-substep 0) and hi->lo distance
 #pragma unroll
@@ -295,17 +314,21 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
       }
-      if (more) {
-        // slots q of this unit: first the next step's weight pieces, then the activation pieces of
-        // the NEXT channel chunk.  The slab buffer of chunk kc+1 is free during all taps of chunk kc,
-        // so its pieces are spread over the taps (piece a goes out on tap a % taps) instead of
-        // bunching on the last tap, where the last of them would have one MFMA group to land.
+      // DMA slots q of this unit: the weight pieces of step s+PD and the activation pieces of the
+      // NEXT channel chunk.  The slab buffer of chunk kc+1 is free during all taps of chunk kc, so
+      // its pieces are spread over the taps (piece a goes out on tap a % taps) instead of bunching
+      // on the last tap.  Two stages: weights first (they must land within this step).  Three
+      // stages: activations first -- the counted wait at the end of the step then leaves exactly
+      // this step's weight pieces in flight and everything older (the slab pieces, the weight tile
+      // of step s+1) has landed.
 #pragma unroll
-        for (int q = u * PPU; q < (u + 1) * PPU && q < PA + PB; ++q) {
-          if (q < PB) {
-            ISSUE_B_PIECE(s + 1, (s + 1) & 1, q)
-          } else if (kc + 1 < nkc) {
-            const int a = (q - PB) * taps + tap;  // wave-uniform
+      for (int q = u * PPU; q < (u + 1) * PPU && q < PA + PB; ++q) {
+        const int qb = NB == 2 ? q : q - PA, qa = NB == 2 ? q - PB : q;
+        if (qb >= 0 && qb < PB) {
+          if (pre) ISSUE_B_PIECE(s + PD, stg_pre, qb)
+        } else if (qa >= 0 && qa < PA) {
+          if (kc + 1 < nkc) {
+            const int a = qa * taps + tap;  // wave-uniform
 #pragma unroll
             for (int ai = 0; ai < PA; ++ai)
               if (a == ai) ISSUE_A_PIECE(kc + 1, (kc + 1) & 1, ai)
@@ -313,8 +336,22 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         }
       }
     }
-    __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
+    if constexpr (NB == 2) {
+      __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
+    } else {
+      // every wave waits for its own older DMAs, then the barrier: after it all pieces of step s+1
+      // (from all waves) are in LDS, and all reads of stage `stg` (restaged next step) are done
+      if (pre) {
+        if (b_full) wait_vm<NP * PB>(); else wait_vm<NP * (PB - 1)>();
+      } else {
+        wait_vm<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     if (last_tap) { tap = 0; ++kc; } else { ++tap; }
+    stg = stg + 1 == NB ? 0 : stg + 1;
   }
 #undef ISSUE_A
 #undef ISSUE_B
@@ -466,6 +503,8 @@ inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR) {
   return tiles;
 }
 
+constexpr int NUM_CUS = 256;
+
 template <int EPI, bool SPLIT, class C>
 int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
@@ -480,13 +519,22 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   return CUBE_OK;
 }
 
-constexpr int NUM_CUS = 256;
-
 template <int EPI, bool SPLIT>
 int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
+  static const int force = getenv("CUBE_GEMM_CFG") ? atoi(getenv("CUBE_GEMM_CFG")) : 0;  // A/B switch (bits)
   // the big tiles need enough row tiles to fill the 256 CUs
   const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
-  if (!big) return launch_cfg<EPI, SPLIT, CfgSmall>(p, cg, st);
+  if (!big) {
+    if constexpr (EPI == CUBE_EPI_GATE) {
+      // a convolution whose 128-row tiles are a little more than one block per CU: 160-row tiles, one round
+      const long nt = p.N / CfgSmall160::BN;
+      const long t160 = count_row_tiles(p.M, cg, CfgSmall160::BM, CfgSmall160::SR);
+      if ((force & 1) && p.taps > 1 && t160 > 0 && t160 * nt <= NUM_CUS &&
+          (long)count_row_tiles(p.M, cg, CfgSmall::BM, CfgSmall::SR) * nt > NUM_CUS * 3 / 4)
+        return launch_cfg<EPI, SPLIT, CfgSmall160>(p, cg, st);
+    }
+    return launch_cfg<EPI, SPLIT, CfgSmall>(p, cg, st);
+  }
   // one block per CU: time ~ rounds x tile height (x a small penalty for the shorter tiles, whose
   // weight-tile traffic and fragment reads are spread over fewer rows)
   const long nt = p.N / CfgBig::BN;
@@ -494,6 +542,9 @@ int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
     const int t = count_row_tiles(p.M, cg, BM, SR);
     return t < 0 ? 1e30 : (double)((t * nt + NUM_CUS - 1) / NUM_CUS) * BM * penalty;
   };
+  if constexpr (EPI == CUBE_EPI_GATE) {
+    if (force & 2) return launch_cfg<EPI, SPLIT, CfgBig192P>(p, cg, st);
+  }
   if (cost(CfgBig192::BM, CfgBig192::SR, 1.04) < cost(CfgBig::BM, CfgBig::SR, 1.0))
     return launch_cfg<EPI, SPLIT, CfgBig192>(p, cg, st);
   return launch_cfg<EPI, SPLIT, CfgBig>(p, cg, st);
