@@ -305,14 +305,18 @@ def pack_parser(sd, cfg, enc_sizes, ext_dims):
     pp_w = pk["pre_out"]["N"]  # width of the pre_parsing buffer (pad columns are tanh(0) = 0)
     pp_perm = np.concatenate([np.arange(cfg.pre_parser_size), -np.ones(pp_w - cfg.pre_parser_size, dtype=np.int64)])
 
-    def biaffine_in(name, hs):
-        """[h1 | 1 | 0.. | h2 | 1 | 0..] with D = pad32(hs+1) columns each; ones via relu(0*x + 1)."""
+    def biaffine_rows(name, hs):
         D = p32(hs + 1)
         w = torch.cat([sd[name + ".W1.weight"], sd[name + ".W2.weight"]], 0).float()
         b = torch.cat([sd[name + ".W1.bias"], sd[name + ".W2.bias"]], 0).float()
         out_rows = -np.ones(2 * D, dtype=np.int64)
         out_rows[:hs] = np.arange(hs)
         out_rows[D:D + hs] = hs + np.arange(hs)
+        return D, w, b, out_rows
+
+    def biaffine_in(name, hs):
+        """[h1 | 1 | 0.. | h2 | 1 | 0..] with D = pad32(hs+1) columns each; ones via relu(0*x + 1)."""
+        D, w, b, out_rows = biaffine_rows(name, hs)
         p = pack_linear(w, b, in_perm=pp_perm, out_rows=out_rows)
         p["bias"][hs] = 1.0
         p["bias"][D + hs] = 1.0
@@ -332,6 +336,16 @@ def pack_parser(sd, cfg, enc_sizes, ext_dims):
     wlp = torch.zeros((n_l, Dl, Dl), dtype=torch.float32)
     wlp[:, :ls + 1, :ls + 1] = wl.permute(0, 2, 1)  # [o][q][p]
     pk["label_bilin"] = dict(W=_bf16(wlp), bias=sd["_label.scorer.W_bilin.bias"].float().contiguous(), D=Dl)
+    # both biaffine input projections read pre_parsing: one GEMM -> [h1;1 | h2;1 | x1;1 | x2;1]
+    # (`_get_labels` on pre_parsing handed in by the caller keeps the separate label_in)
+    _, wh_, bh_, rh_ = biaffine_rows("_head", hs)
+    _, wl_, bl_, rl_ = biaffine_rows("_label", ls)
+    rows = np.concatenate([rh_, np.where(rl_ >= 0, rl_ + wh_.shape[0], -1)])
+    p = pack_linear(torch.cat([wh_, wl_], 0), torch.cat([bh_, bl_], 0), in_perm=pp_perm, out_rows=rows)
+    for c in (hs, Dh + hs, 2 * Dh + ls, 2 * Dh + Dl + ls):
+        p["bias"][c] = 1.0
+    p["Dh"], p["Dl"] = Dh, Dl
+    pk["bi_in"] = p
     return pk, lay
 
 

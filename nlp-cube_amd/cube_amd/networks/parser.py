@@ -481,40 +481,48 @@ class Parser(_HipNet):
         pp = buf.get("pp_%d" % slot, BT, pp_w)  # per slot: read by the decode stage while the next batch is encoded
         hip.gemm(src, src_ld, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pp, ldo0=pp_w,
                  n_valid=q["n_valid"], stream=st)
-        q = pk["head_in"]
-        Dh = q["D"]
-        ha = buf.get("ha", BT, 2 * Dh)
-        hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=ha, ldo0=2 * Dh,
-                 n_valid=2 * Dh, stream=st)
+        # both biaffine input projections in one launch: HAL = [h1;1 | h2;1 | x1;1 | x2;1] (arc scorer
+        # inputs, then the label scorer's; per slot: the label scorer reads it in the decode stage)
+        q = pk["bi_in"]
+        Dh, Dl = q["Dh"], q["Dl"]
+        hal_w = 2 * Dh + 2 * Dl
+        hal = buf.get("hal_%d" % slot, BT, hal_w)
+        hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hal, ldo0=hal_w,
+                 n_valid=hal_w, stream=st)
         q = pk["head_bilin"]
         u = buf.get("u", BT, Dh)
-        hip.gemm(ha, 2 * Dh, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
+        hip.gemm(hal, hal_w, BT, q["K"], q["W"], q["N"], None, hip.EPI_BF16, out0=u, ldo0=Dh, n_valid=Dh, stream=st)
         arc_logits = buf.get("arc_logits_%d" % slot, B * L, T, torch.float32)[:B * L * T].view(B, L, T)
         arc_probs = buf.get("arc_probs_%d" % slot, B * L, T, torch.float32)[:B * L * T].view(B, L, T)
-        hip.check(lib.cube_biaffine_arc(u.hi.data_ptr(), lo(u.lo), Dh, ha.hi.data_ptr(), lo(ha.lo), 2 * Dh, Dh, Dh, B, T,
+        hip.check(lib.cube_biaffine_arc(u.hi.data_ptr(), lo(u.lo), Dh, hal.hi.data_ptr(), lo(hal.lo), hal_w, Dh, Dh, B, T,
                                         arc_logits.data_ptr(), arc_probs.data_ptr(), st), "cube_biaffine_arc")
+        fr.update(hal=hal, hal_w=hal_w, hl_col=2 * Dh)
         fr.update(arc_logits=arc_logits, arc_probs=arc_probs, pp=pp, pp_w=pp_w)
         return fr
 
     def _encode(self, bt, want_aux=False, slot=0):
         return self._back(bt, self._front(bt, slot, want_aux), slot)
 
-    def _label_scores(self, bt, pp, pp_w, heads_dev, labels_out=None):
-        """parser.py:218-233: gather head rows + DeepBiaffine(pairwise=False), fused on device."""
+    def _label_scores(self, bt, pp, pp_w, heads_dev, labels_out=None, hl=None, hl_w=0, hl_col=0):
+        """parser.py:218-233: gather head rows + DeepBiaffine(pairwise=False), fused on device.
+        hl (with its leading dimension and first column): the [x1;1 | x2;1] projections when the encode
+        stage has already made them (`_back`); else they are computed here from `pp`."""
         lib, pk, st = hip.load(), self._pk, hip.stream_handle()
         B, L, T = bt["B"], bt["L"], bt["T"]
         BT = B * T
         q = pk["label_in"]
         Dl = q["D"]
-        hl = self._buf.get("hl", BT, 2 * Dl)
-        hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hl, ldo0=2 * Dl,
-                 n_valid=2 * Dl, stream=st)
+        if hl is None:
+            hl, hl_w, hl_col = self._buf.get("hl", BT, 2 * Dl), 2 * Dl, 0
+            hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hl, ldo0=2 * Dl,
+                     n_valid=2 * Dl, stream=st)
         n_l = self._sizes["labels"]
         logits = self._buf.get("label_logits", B * L, n_l, torch.float32)[:B * L * n_l].view(B, L, n_l)
         labels = labels_out if labels_out is not None else \
             self._buf.get("labels", B, L, torch.int32)[:B * L].view(B, L)
         lb = pk["label_bilin"]
-        hip.check(lib.cube_label_score(hl.hi.data_ptr(), hip.ptr(hl.lo), 2 * Dl, Dl, Dl, lb["W"].hi.data_ptr(),
+        hl_hi, hl_lo = hip._planes(hl, hl_col)
+        hip.check(lib.cube_label_score(hl_hi, hl_lo, hl_w, Dl, Dl, lb["W"].hi.data_ptr(),
                                        hip.ptr(lb["W"].lo), lb["bias"].data_ptr(), n_l, heads_dev.data_ptr(),
                                        bt["lens"].data_ptr(), B, L, logits.data_ptr(), labels.data_ptr(), st),
                   "cube_label_score")
@@ -531,7 +539,8 @@ class Parser(_HipNet):
         hip.check(hip.load().cube_mst_decode(r["arc_probs"].data_ptr(), bt["lens"].data_ptr(), B, L,
                                              packed[0].data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                              hip.stream_handle()), "cube_mst_decode")
-        label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], packed[0], labels_out=packed[1])
+        label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], packed[0], labels_out=packed[1],
+                                                  hl=r["hal"], hl_w=r["hal_w"], hl_col=r["hl_col"])
         packed[2].copy_(r["upos"])
         packed[3].copy_(r["xpos"])
         packed[4].copy_(r["attrs"])

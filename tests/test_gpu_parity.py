@@ -644,3 +644,39 @@ def test_merged_reference_batches_do_not_change_results(dev):
     t.process(tdocs[0], MorphoCollate(tenc), batch_size=8, merge=True)
     t.process(tdocs[1], MorphoCollate(tenc), batch_size=8, merge=False)
     assert str(tdocs[0]) == str(tdocs[1])
+
+
+def test_pipelined_submit_equals_serial_decode(dev):
+    """`submit` / `collect` (three stage streams, N_SLOTS batches in flight, slot buffers reused) give
+    bit-identical result arrays to the single-stream `decode_batch_prepared`, for batches of different
+    shapes interleaved, twice around the slots."""
+    from collections import deque
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    col = MorphoCollate(enc)
+    rng = np.random.default_rng(5)
+    bts = []
+    for i in range(7):
+        lens = rng.integers(1, 12, size=int(rng.integers(3, 40)))
+        doc = synth.make_document(enc, lens, seed=900 + i, ext_word_emb=case["ext"], max_word_len=6)
+        X = col.collate_fn(doc.sentences, targets=False)
+        X.pop("y_upos", None)
+        bts.append(p._prepare(X))
+    serial = []
+    for bt in bts:
+        r = p.decode_batch_prepared(bt)
+        serial.append((r["packed"].cpu().numpy().copy(), r["status"].cpu().numpy().copy()))
+    inflight, got = deque(), []
+    for bt in bts * 2:
+        inflight.append(p.submit(bt))
+        if len(inflight) == p.N_SLOTS:
+            got.append(p.collect(inflight.popleft()))
+    while inflight:
+        got.append(p.collect(inflight.popleft()))
+    assert len(got) == 2 * len(bts)
+    for k, (packed, status) in enumerate(got):
+        exp_p, exp_s = serial[k % len(bts)]
+        assert np.array_equal(packed, exp_p), k
+        assert np.array_equal(status, exp_s), k
