@@ -43,9 +43,10 @@ struct CfgSmall { static constexpr int BM = 128, BN = 128, WM = 4, WN = 2, SR = 
 struct CfgBig192 { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 272, NB = 2; };
 // NB = weight-tile stages in LDS.  With three, the weight tile of step s+2 is in flight while step s
 // runs: the end-of-step wait is a COUNTED vmcnt (that prefetch stays outstanding across a raw
-// s_barrier) instead of the full drain a two-stage ring needs.  The third stage is paid for with a
-// shorter activation slab (ragged groups: a few rows fewer per tile).
-struct CfgBig192P { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR = 240, NB = 3; };
+// s_barrier) instead of the full drain a two-stage ring needs.  Measured: +12 % on the few-row
+// convolutions below; nothing on the 192/256-row tiles (a 192-row, three-stage variant ran at the
+// speed of the two-stage one: at the clock the chip holds under this load those are MFMA-bound, not
+// latency-bound), which therefore keep two stages and the longer activation slab.
 // few-row convolutions whose 128-row tiles would be a little over one block per CU: 160-row tiles on
 // 10 waves (5x2), one block per CU, three weight stages
 struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR = 176, NB = 3; };
@@ -521,7 +522,6 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
 
 template <int EPI, bool SPLIT>
 int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
-  static const int force = getenv("CUBE_GEMM_CFG") ? atoi(getenv("CUBE_GEMM_CFG")) : 0;  // A/B switch (bits)
   // the big tiles need enough row tiles to fill the 256 CUs
   const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
   if (!big) {
@@ -529,7 +529,7 @@ int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
       // a convolution whose 128-row tiles are a little more than one block per CU: 160-row tiles, one round
       const long nt = p.N / CfgSmall160::BN;
       const long t160 = count_row_tiles(p.M, cg, CfgSmall160::BM, CfgSmall160::SR);
-      if ((force & 1) && p.taps > 1 && t160 > 0 && t160 * nt <= NUM_CUS &&
+      if (p.taps > 1 && t160 > 0 && t160 * nt <= NUM_CUS &&
           (long)count_row_tiles(p.M, cg, CfgSmall::BM, CfgSmall::SR) * nt > NUM_CUS * 3 / 4)
         return launch_cfg<EPI, SPLIT, CfgSmall160>(p, cg, st);
     }
@@ -542,9 +542,6 @@ int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
     const int t = count_row_tiles(p.M, cg, BM, SR);
     return t < 0 ? 1e30 : (double)((t * nt + NUM_CUS - 1) / NUM_CUS) * BM * penalty;
   };
-  if constexpr (EPI == CUBE_EPI_GATE) {
-    if (force & 2) return launch_cfg<EPI, SPLIT, CfgBig192P>(p, cg, st);
-  }
   if (cost(CfgBig192::BM, CfgBig192::SR, 1.04) < cost(CfgBig::BM, CfgBig::SR, 1.0))
     return launch_cfg<EPI, SPLIT, CfgBig192>(p, cg, st);
   return launch_cfg<EPI, SPLIT, CfgBig>(p, cg, st);

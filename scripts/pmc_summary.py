@@ -1,0 +1,31 @@
+"""Mean FETCH_SIZE / WRITE_SIZE (KB) per launch of the char-conv GEMM (gate epilogue, big tiles) from the
+two rocprofv3 --pmc CSVs -> profiles/<name>_traffic.json.
+    python scripts/pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv out.json"""
+import csv
+import json
+import sys
+
+
+def mean_kb(path, counter):
+    vals = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            n = r["Kernel_Name"]
+            if "gemm_kernel<4" in n and "CfgBig" in n and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return sum(vals) / max(len(vals), 1), len(vals)
+
+
+fetch, nf = mean_kb(sys.argv[1], "FETCH_SIZE")
+write, nw = mean_kb(sys.argv[2], "WRITE_SIZE")
+out = {
+    "kernel": "gemm_kernel<GATE, bf16x3, big tiles> (char conv, layers>=1)", "config": 1,
+    "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches": [nf, nw],
+    "correction": "gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads (LDS-DMA) at 64 bytes: "
+                  "doubled; WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",
+    "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
+    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `bench.py --steps 5 --warmup 2` "
+           "(scripts/pmc_traffic.sh), mean over the launches of char layers 1-4",
+}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
