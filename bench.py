@@ -197,7 +197,7 @@ def main():
                     flops_per_launch=flops_per_launch, padded_W=bt["W"], rows_algorithmic=NW, rows_executed=rows_exec,
                     mfma_flops_executed_per_launch=flops_executed,
                     mfma_executed_tflops=flops_executed / (ms * 1e-3) / 1e12 if ms else 0.0,
-                    note="launches timed while the second pipeline stream runs beside them")
+                    note="launches timed while the other pipeline streams run beside them")
     out = {
         "metric": "sentences/sec (node) parser+tagger inference", "value": sent_per_s, "unit": "sentences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
