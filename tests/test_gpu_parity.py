@@ -92,7 +92,8 @@ def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("M,seq,Kc,half", [(6 * 11, 11, 64, 80), (11 * 2400, 11, 64, 256)])  # small / 256x256 tiles
+@pytest.mark.parametrize("M,seq,Kc,half", [(6 * 11, 11, 64, 80), (11 * 2400, 11, 64, 256),  # small / 256x256 tiles
+                                           (11 * 700, 11, 96, 256)])  # 160-row tiles, three weight stages
 def test_gemm_gate_epilogue_and_rowmap(dev, split, M, seq, Kc, half):
     from cube_amd import hip
     from cube_amd.networks import packing
