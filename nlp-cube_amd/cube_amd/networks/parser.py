@@ -715,10 +715,11 @@ class Parser(_HipNet):
         if not merge or len(starts) < 2:
             self._run_batches((sents[start:start + batch_size], start) for start in starts)
             return doc
-        from cube_amd.sharding import merged_reference_batches
-        keys = [(max(len(s.words) for s in sents[a:a + batch_size]),
-                 max((len(w.word) for s in sents[a:a + batch_size] for w in s.words), default=0)) for a in starts]
-        groups = merged_reference_batches(keys, batch_size, lambda k: min(1024, max_tokens // (k[0] + 1)))
+        from cube_amd.sharding import merged_reference_batches, sentence_batch_keys
+
+        def cap(k):
+            return min(1024, max_tokens // (k[0] + 1))
+        groups = merged_reference_batches(sentence_batch_keys(sents, starts, batch_size, cap), batch_size, cap)
 
         def batches():
             for g in groups:

@@ -90,10 +90,11 @@ class Tagger(_HipNet):
         sents = doc.sentences
         starts = list(range(0, len(sents), batch_size))
         if merge and len(starts) > 1:
-            from cube_amd.sharding import merged_reference_batches
-            keys = [(max(len(s.words) for s in sents[a:a + batch_size]),
-                     max((len(w.word) for s in sents[a:a + batch_size] for w in s.words), default=0)) for a in starts]
-            groups = merged_reference_batches(keys, batch_size, lambda k: min(1024, max_tokens // max(k[0], 1)))
+            from cube_amd.sharding import merged_reference_batches, sentence_batch_keys
+
+            def cap(k):
+                return min(1024, max_tokens // max(k[0], 1))
+            groups = merged_reference_batches(sentence_batch_keys(sents, starts, batch_size, cap), batch_size, cap)
             device_batches = [[s for r in g for s in sents[starts[r]:starts[r] + batch_size]] for g in groups]
         else:
             device_batches = [sents[a:a + batch_size] for a in starts]

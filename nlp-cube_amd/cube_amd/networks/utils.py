@@ -10,7 +10,7 @@ the GPU.
 import numpy as np
 import torch
 
-from cube_amd import hip
+from cube_amd import hip, host
 
 
 class MorphoDataset:
@@ -74,22 +74,24 @@ class MorphoCollate:
         # flat character stream (UTF-32 code points of all words) -> (word, position) scatter
         cps = np.frombuffer("".join(texts).encode("utf-32-le", "surrogatepass"), dtype=np.uint32).astype(np.int64)
         tab = self._char_tables(cps)
-        wi = np.repeat(np.arange(N), word_len)
-        starts = np.cumsum(word_len) - word_len
-        pi = np.arange(len(wi)) - np.repeat(starts, word_len)
         x_word = np.zeros((N, W), dtype=np.int64)
         x_word_case = np.zeros((N, W), dtype=np.int64)
-        x_word_masks = np.zeros((N, W), dtype=np.float64)
-        x_word[wi, pi] = tab[0, cps]
-        x_word_case[wi, pi] = tab[1, cps]
-        x_word_masks[wi, pi] = 1
+        inside = np.arange(W)[None, :] < word_len[:, None]   # position < word length
+        x_word_masks = inside.astype(np.float64)
+        hm = host.load()
+        if hm is not None:
+            hm.fill_ragged(np.ascontiguousarray(tab[0, cps]), word_len, x_word, W)
+            hm.fill_ragged(np.ascontiguousarray(tab[1, cps]), word_len, x_word_case, W)
+        else:  # row-major order of `inside` = the order of the character stream
+            x_word[inside] = tab[0, cps]
+            x_word_case[inside] = tab[1, cps]
         sb = np.repeat(np.arange(B), sent_len)
         si = np.arange(N) - np.repeat(np.cumsum(sent_len) - sent_len, sent_len)
         x_sent = np.zeros((B, L), dtype=np.int64)
         x_sent_masks = np.zeros((B, L), dtype=np.float64)
         # word ids (lower-cased look-up, utils.py:284-289) through a cache keyed by the raw token
         wid = self._wid_cache
-        ids = [wid.get(t) for t in texts]
+        ids = list(map(wid.get, texts))
         if None in ids:
             if len(wid) > (1 << 20):
                 wid.clear()
@@ -103,10 +105,19 @@ class MorphoCollate:
         embs = []
         for k in range(K):
             rows = [w.emb[k] for w in words]
-            try:
-                e = np.concatenate(rows).reshape(N, -1)
-            except ValueError:  # not arrays of one length: let NumPy sort it out the slow way
-                e = np.asarray(rows)
+            e = None
+            r0 = rows[0]
+            if hm is not None and isinstance(r0, np.ndarray) and r0.ndim == 1:
+                e = np.empty((N, r0.shape[0]), dtype=r0.dtype)
+                try:
+                    hm.stack_rows(rows, e)  # one memcpy per word
+                except (ValueError, TypeError, BufferError):  # rows of other sizes / kinds: the general way below
+                    e = None
+            if e is None:
+                try:
+                    e = np.concatenate(rows).reshape(N, -1)
+                except ValueError:  # not arrays of one length: let NumPy sort it out the slow way
+                    e = np.asarray(rows)
             embs.append(torch.from_numpy(np.ascontiguousarray(e)))
         out = {
             "x_sent": torch.from_numpy(x_sent), "x_lang_sent": torch.from_numpy(x_lang_sent),

@@ -56,6 +56,22 @@ def merged_reference_batches(keys, batch_size, cap):
     return out
 
 
+def sentence_batch_keys(sents, starts, batch_size, cap):
+    """Padding geometry (longest sentence, longest word) of each reference batch of sentences, for
+    `merged_reference_batches`.  The longest word costs a pass over every word, so it is only looked
+    up for batches that can merge at all (`cap(key) >= 2 * batch_size`, which the longest sentence
+    decides); the others get a key of their own."""
+    keys = []
+    for a in starts:
+        group = sents[a:a + batch_size]
+        lmax = max(len(s.words) for s in group)
+        if cap((lmax, 0)) < 2 * batch_size:
+            keys.append((lmax, -1 - a))
+        else:
+            keys.append((lmax, max((len(w.word) for s in group for w in s.words), default=0)))
+    return keys
+
+
 class _Slice:
     """A view of a Document holding only sentences[lo:hi] (same Sentence objects)."""
 
