@@ -215,3 +215,47 @@ def test_abi_rejects_bad_arguments():
     assert lib.cube_mst_workspace_bytes(4, 200) > lib.cube_mst_workspace_bytes(4, 100) > 0
     assert "D/columns" in err(lib.cube_label_score(P, None, 448, 224, 288, P, None, P, 10, P, P, 2, 3, P, P, None))
     assert "bad args" in err(lib.cube_ext_finish(P, 8, 2, 3, 2, 2, 1, P, None, 64, 0, None, None, 0, 0, None))  # root = 2
+
+
+def test_host_helper_matches_numpy_collate(monkeypatch):
+    """`_cube_host` (csrc/host_collate.c) only replaces two bulk copies: the collate result with it is
+    identical to the NumPy-only path (which the golden G1 vectors pin), and it rejects rows it cannot
+    stack (the collate then falls back to NumPy's general conversion)."""
+    from cube_amd import host
+    hm = host.load()
+    assert hm is not None, "build() compiles _cube_host.so"
+    enc = synth.make_encodings()
+    doc = synth.make_document(enc, [3, 1, 17, 8, 1, 30], seed=4, ext_word_emb=(24, 7))
+    col = MorphoCollate(enc)
+    a = col.collate_fn(doc.sentences)
+    monkeypatch.setattr(host, "_mod", None)
+    b = col.collate_fn(doc.sentences)
+    monkeypatch.undo()
+    assert a.keys() == b.keys()
+    for k in a:
+        if k == "x_word_embeddings":
+            assert len(a[k]) == len(b[k]) == 2 and all(torch.equal(x, y) and x.dtype == y.dtype for x, y in zip(a[k], b[k]))
+        else:
+            assert torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype, k
+    rows = [np.arange(5, dtype=np.float32) + i for i in range(4)]
+    out = np.empty((4, 5), dtype=np.float32)
+    hm.stack_rows(rows, out)
+    assert np.array_equal(out, np.stack(rows))
+    for bad in (rows[:3] + [np.arange(6, dtype=np.float32)],            # another length
+                rows[:3] + [np.arange(5, dtype=np.int32)],              # another element type, same bytes
+                rows[:3] + [np.arange(10, dtype=np.float32)[::2]],      # not contiguous
+                rows[:3] + [[0.0] * 5]):                                # not a buffer
+        with pytest.raises((ValueError, TypeError, BufferError)):
+            hm.stack_rows(bad, np.empty((4, 5), dtype=np.float32))
+    o = np.zeros((3, 4), dtype=np.int64)
+    hm.fill_ragged(np.arange(1, 6, dtype=np.int64), np.array([2, 0, 3], dtype=np.int64), o, 4)
+    assert o.tolist() == [[1, 2, 0, 0], [0, 0, 0, 0], [3, 4, 5, 0]]
+    for flat, lens in ((np.arange(5), [2, 0, 2]), (np.arange(5), [5, 0, 0]), (np.arange(5), [-1, 3, 3])):
+        with pytest.raises(ValueError):
+            hm.fill_ragged(np.asarray(flat, dtype=np.int64), np.asarray(lens, dtype=np.int64), np.zeros((3, 4), dtype=np.int64), 4)
+    # words whose embeddings are plain lists (not arrays) still collate
+    for s in doc.sentences:
+        for w in s.words:
+            w.emb = [e.tolist() for e in w.emb]
+    c = col.collate_fn(doc.sentences)
+    assert all(torch.allclose(x.float(), y.float()) for x, y in zip(c["x_word_embeddings"], a["x_word_embeddings"]))
