@@ -28,7 +28,13 @@ namespace {
 
 constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
 constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences (node ids are bytes): S lives in the workspace (HBM/L2), slow but exact
-constexpr int MST_GLOBAL_ROOT_BLOCKS = 256;  // workgroups (= private score matrices) of the root kernel in that mode
+constexpr int MST_GLOBAL_ROOT_BLOCKS = 1792;  // workgroups (= private score matrices) of the root kernel in that mode: 7 per CU
+// The rooted re-runs (one task per candidate root, ~17 per sentence when most first trees are not
+// single-rooted) switch to workspace-resident score matrices earlier: from this size on an LDS-resident
+// matrix leaves one or two tasks per CU, and a task is bound by its own dependent-access latency, not
+// by where S lives (129 nodes: 1088 tasks in 5 rounds of 3 ms with S in LDS, all at once in 5.5 ms
+// with S in the workspace; the first pass, one task per sentence, stays in LDS)
+constexpr int MST_ROOT_GLOBAL_N = 96;  // workgroups (= private score matrices) of the root kernel in that mode
 
 struct MstLds {
   double* S; int ld;
@@ -345,10 +351,15 @@ struct MstWs {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ inline size_t mst_s_elems(int L) { return (size_t)(L + 1) * ((L + 1) | 1); }
+__host__ inline size_t mst_root_blocks(int B, int L) {  // workgroups of the root kernel in workspace mode
+  const size_t nt = (size_t)B * L;
+  return nt < (size_t)MST_GLOBAL_ROOT_BLOCKS ? nt : (size_t)MST_GLOBAL_ROOT_BLOCKS;
+}
 __host__ inline size_t mst_ws_bytes(int B, int L) {
   const size_t nt = (size_t)B * L;
   size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1));
-  if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * ((size_t)B + MST_GLOBAL_ROOT_BLOCKS);
+  if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * (size_t)B;
+  if (L + 1 >= MST_ROOT_GLOBAL_N) b += 8 * mst_s_elems(L) * mst_root_blocks(B, L);
   return b;
 }
 __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
@@ -528,26 +539,26 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
   if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
   if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const bool gs = L + 1 > MST_MAX_N;
-  const size_t lds = mst_lds_bytes(L + 1, gs);
+  const bool gs_first = L + 1 > MST_MAX_N, gs_root = L + 1 >= MST_ROOT_GLOBAL_N;
+  const size_t lds_first = mst_lds_bytes(L + 1, gs_first), lds_root = mst_lds_bytes(L + 1, gs_root);
   static CubeLdsReservation reserved[4];
-  const void* fns[4] = {(const void*)mst_first_kernel<false>, (const void*)mst_root_kernel<false>,
-                        (const void*)mst_first_kernel<true>, (const void*)mst_root_kernel<true>};
-  for (int k = gs ? 2 : 0; k < (gs ? 4 : 2); ++k)
-    if (!reserved[k].ensure(fns[k], lds)) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds);
+  const void* fn_first = gs_first ? (const void*)mst_first_kernel<true> : (const void*)mst_first_kernel<false>;
+  const void* fn_root = gs_root ? (const void*)mst_root_kernel<true> : (const void*)mst_root_kernel<false>;
+  if (!reserved[gs_first ? 2 : 0].ensure(fn_first, lds_first) || !reserved[gs_root ? 3 : 1].ensure(fn_root, lds_root))
+    CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds_first > lds_root ? lds_first : lds_root);
   MstWs ws = mst_ws_carve(workspace, B, L);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
-  int nblk = B * L;
-  if (nblk > 4096) nblk = 4096;
-  if (gs) {
-    if (nblk > MST_GLOBAL_ROOT_BLOCKS) nblk = MST_GLOBAL_ROOT_BLOCKS;
-    hipLaunchKernelGGL(mst_first_kernel<true>, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
-    CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
-    hipLaunchKernelGGL(mst_root_kernel<true>, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+  if (gs_first)
+    hipLaunchKernelGGL(mst_first_kernel<true>, dim3(B), dim3(64), lds_first, st, probs, lens, B, L, heads, status, ws);
+  else
+    hipLaunchKernelGGL(mst_first_kernel<false>, dim3(B), dim3(64), lds_first, st, probs, lens, B, L, heads, status, ws);
+  CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
+  if (gs_root) {
+    hipLaunchKernelGGL(mst_root_kernel<true>, dim3((unsigned)mst_root_blocks(B, L)), dim3(64), lds_root, st, probs, lens, B, L, ws);
   } else {
-    hipLaunchKernelGGL(mst_first_kernel<false>, dim3(B), dim3(64), lds, st, probs, lens, B, L, heads, status, ws);
-    CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
-    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64), lds, st, probs, lens, B, L, ws);
+    int nblk = B * L;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64), lds_root, st, probs, lens, B, L, ws);
   }
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
   hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);

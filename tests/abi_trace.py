@@ -216,8 +216,10 @@ class TraceLib:
         a16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
         nt = B * L
         b = 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * (L + 1))
-        if L + 1 > 130:  # long-sentence mode: score matrices in the workspace
-            b += 8 * (L + 1) * ((L + 1) | 1) * (B + 256)
+        if L + 1 > 130:  # long-sentence mode: score matrices of the first pass in the workspace
+            b += 8 * (L + 1) * ((L + 1) | 1) * B
+        if L + 1 >= 96:  # the rooted re-runs keep theirs there from 96 nodes on (one per workgroup)
+            b += 8 * (L + 1) * ((L + 1) | 1) * min(nt, 1792)
         return b
 
     def cube_mst_decode(self, probs, lens, B, L, heads, status, ws, ws_bytes, stream):
