@@ -681,3 +681,22 @@ def test_pipelined_submit_equals_serial_decode(dev):
         exp_p, exp_s = serial[k % len(bts)]
         assert np.array_equal(packed, exp_p), k
         assert np.array_equal(status, exp_s), k
+
+
+@pytest.mark.parametrize("n_chars", [40, 300])
+def test_very_long_words_match_oracle(dev, n_chars):
+    """A token far longer than any tile's activation slab (a URL, a hash): the character CNN still
+    follows the reference (no truncation in utils.py:291-304), arc scores within tolerance."""
+    from oracle import parser_oracle
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    doc = cases.document(case, enc, "ragged")
+    doc.sentences[1].words[0].word = ("Ab" * n_chars)[:n_chars]
+    X = MorphoCollate(enc).collate_fn(doc.sentences)
+    X.pop("y_upos")
+    r = p.decode_batch(X)
+    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="fp32")
+    with torch.no_grad():
+        e = ora.decode_batch(parser_oracle.collate(doc.sentences, enc))
+    assert _rel(r["arc_logits"].cpu().numpy(), e["arc_logits"]) < REL_TOL
