@@ -1,7 +1,8 @@
-"""Race / equivalence screen for a GEMM configuration: the bench batches are decoded REPS times in one
-process and every result must be bitwise equal to the first; the arrays are saved so that runs under
-different CUBE_GEMM_CFG values can be compared bitwise (the accumulation order per output element does
-not depend on the tile shape).   python scripts/cfg_check.py out.npz [reps]"""
+"""Race / equivalence screen for a change of GEMM tile configuration: the bench batches are decoded REPS
+times in one process and every result must be bitwise equal to the first; the arrays are saved so that
+runs of two builds (or tile selections) can be compared bitwise with scripts/npz_equal.py -- the
+accumulation order per output element does not depend on the tile shape, so they must be identical.
+    python scripts/cfg_check.py out.npz [reps]"""
 import os
 import sys
 
