@@ -104,21 +104,31 @@ __global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int
     for (int j = 0; j < 8; ++j) sk[j] = 0.f;
     const uint16_t* hi = ly.hi[k] + base;
     const uint16_t* lo = ly.lo[k] ? ly.lo[k] + base : nullptr;
-    for (int q = 0; q < l; ++q) {
-      const uint4 v = *reinterpret_cast<const uint4*>(hi + (size_t)q * ld_x);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    // four positions (eight 16-byte loads) in flight per thread; summed in position order, hi then lo
+    for (int q0 = 0; q0 < l; q0 += 4) {
+      uint4 v[4], u[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        sk[2 * j] += __uint_as_float(w[j] << 16);
-        sk[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      for (int i = 0; i < 4; ++i) {
+        const int q = min(q0 + i, l - 1);
+        v[i] = *reinterpret_cast<const uint4*>(hi + (size_t)q * ld_x);
+        if (lo) u[i] = *reinterpret_cast<const uint4*>(lo + (size_t)q * ld_x);
       }
-      if (lo) {
-        const uint4 u = *reinterpret_cast<const uint4*>(lo + (size_t)q * ld_x);
-        const uint32_t x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (q0 + i >= l) break;
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          sk[2 * j] += __uint_as_float(x[j] << 16);
-          sk[2 * j + 1] += __uint_as_float(x[j] & 0xffff0000u);
+          sk[2 * j] += __uint_as_float(w[j] << 16);
+          sk[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+        if (lo) {
+          const uint32_t x[4] = {u[i].x, u[i].y, u[i].z, u[i].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sk[2 * j] += __uint_as_float(x[j] << 16);
+            sk[2 * j + 1] += __uint_as_float(x[j] & 0xffff0000u);
+          }
         }
       }
     }
@@ -175,15 +185,30 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   unsigned mask = 0;
   const size_t F = 2 * (size_t)half;
-  for (int t = 0; t < taps; ++t) {
+  // all character codes first, then all table rows (ten 16-byte loads in flight), then the sums in tap order
+  int code[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
     const int pp = pos + t - (taps >> 1);
-    if (pp < 0 || pp >= seq_in) continue;
-    mask |= 1u << t;
-    const float* tp = T + ((size_t)t * n_combo + cc[in0 + t]) * F + c4;
-    const float4 va = *reinterpret_cast<const float4*>(tp);
-    const float4 vb = *reinterpret_cast<const float4*>(tp + half);
-    a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
-    b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+    const bool ok = t < taps && pp >= 0 && pp < seq_in;
+    if (ok) mask |= 1u << t;
+    code[t] = ok ? cc[in0 + t] : 0;
+  }
+  float4 va[5], vb[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    if ((mask >> t) & 1u) {
+      const float* tp = T + ((size_t)t * n_combo + code[t]) * F + c4;
+      va[t] = *reinterpret_cast<const float4*>(tp);
+      vb[t] = *reinterpret_cast<const float4*>(tp + half);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    if ((mask >> t) & 1u) {
+      a.x += va[t].x; a.y += va[t].y; a.z += va[t].z; a.w += va[t].w;
+      b.x += vb[t].x; b.y += vb[t].y; b.z += vb[t].z; b.w += vb[t].w;
+    }
   }
   const float* bp = btab + ((size_t)lang_word[cg.word0[g] + j] * 32 + mask) * F + c4;
   const float4 ba = *reinterpret_cast<const float4*>(bp);
