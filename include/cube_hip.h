@@ -140,6 +140,30 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
                            const cube_conv_groups* groups, int taps, int half, int n_combo,
                            void* out, void* out_lo, int ld_out, void* stream);
 
+/* ---- int8x2 fixed point for the gated convolutions whose inputs are gate outputs (|x| < 1) --------
+ * Same reference calls as cube_gemm_bf16 / cube_char_conv0_lookup / cube_masked_mean (modules.py:462-483:
+ * character-CNN layers >= 1), other operand format.  An activation is two int8 planes,
+ *   x = (128*hi + lo) / CUBE_I8_ONE,   hi in [-127, 127], lo in [-64, 63]   (|x| <= 1, step 6.2e-5),
+ * a weight row n likewise with its own scale: w[n, k] = (128*hi + lo) * wmax[n] / CUBE_I8_ONE.  The
+ * products hi*hi and hi*lo + lo*hi are accumulated EXACTLY in int32 on the matrix cores
+ * (v_mfma_i32_32x32x32_i8, twice the bf16 rate; lo*lo, 2^-14 relative, is dropped) and
+ *   C[r, n] = (128*HH + CROSS) * w_scale[n] + bias,    w_scale[n] = 128 * wmax[n] / CUBE_I8_ONE^2.
+ * cube_gemm_i8x2: cube_gemm_args as above with A, A_lo int8 [M, lda], W, W_lo int8 [N, taps*Kc] laid out
+ * in 64-channel chunks (W[n, (kc*taps + tap)*64 + c64]), Kc % 64 == 0, lda % 16 == 0, lda / Kc / ldo0 /
+ * col0 counted in int8 elements; CUBE_EPI_GATE only, no res / out1 / out2 / rowmap; out0, out0_lo int8
+ * planes of the gate values (n_valid, ldo0, col0 multiples of 16).  w_scale f32 [N] in packed column
+ * order.  bias / bias_tab / row_group / groups as for cube_gemm_bf16.
+ * cube_char_conv0_lookup_i8 / cube_masked_mean_i8: the bf16 entry points with int8x2 planes as the
+ * gate-value output / as the layer inputs (ld_out resp. ld_x in int8 elements, multiples of 16 resp. C % 16 == 0). */
+#define CUBE_I8_ONE 16256 /* 127 * 128 */
+int cube_gemm_i8x2(const cube_gemm_args* args, const float* w_scale, void* stream);
+int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                              const cube_conv_groups* groups, int taps, int half, int n_combo,
+                              void* out, void* out_lo, int ld_out, void* stream);
+int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                        int ld_x, const int32_t* len, int N, int W, int C,
+                        void* out, void* out_lo, int ld_out, const int32_t* word_rows, void* stream);
+
 /* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
  * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);
  * root = 1: the destination keeps a root row in front of every sentence (parser.py:195-197),

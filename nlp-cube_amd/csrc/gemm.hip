@@ -16,6 +16,8 @@
 //
 // Epilogues are fused: bias, tanh / relu, the tanh*sigmoid gate with residual accumulation,
 // row scatter (unpack), hi/lo splitting of bf16 outputs.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/cube_hip.h"
 
@@ -50,6 +52,10 @@ struct CfgBig192 { static constexpr int BM = 192, BN = 256, WM = 2, WN = 4, SR =
 // few-row convolutions whose 128-row tiles would be a little over one block per CU: 160-row tiles on
 // 10 waves (5x2), one block per CU, three weight stages
 struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR = 176, NB = 3; };
+// int8x2 operands (cube_gemm_i8x2): two int32 accumulator sets per output (the slice products differ
+// by 2^7), so a wave keeps 64x64; 256x128 / 8 waves (4x2).  Tall and narrow: the activation slab is
+// staged once per 5 taps, the weight tile once per tap, so rows are the cheaper side to extend.
+struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 2; };
 
 constexpr int MAX_TAPS = 5;
 template <class C> constexpr int slab_rows() { return C::SR; }
@@ -79,6 +85,7 @@ struct GemmParams {
   int m_tiles; int n_tiles;  // set by launch_cfg
   int vec_out;               // gate epilogue without residual: 16-byte row-contiguous stores are legal
   const float* bias_tab; const int32_t* row_group;  // row-dependent bias (broadcast channels folded in)
+  const float* w_scale;      // int8x2 only: per packed column, value of one unit of 128*hh + (hl + lh)
 };
 
 // Ragged sequence groups (host struct cube_conv_groups passed by value): group g owns input rows
@@ -114,8 +121,16 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 // HBM/L2 -> LDS once per output tile instead of once per tap.  Rows that a tap would take from a
 // neighbouring sequence (Conv1d zero padding) are redirected, per lane, to a zero row in LDS.
 // Both operands go global -> LDS by LDS-DMA (no staging registers, no ds_write), one k-step ahead.
-template <int EPI, bool SPLIT, class C>
+//
+// I8 ("int8x2", cube_gemm_i8x2): the same kernel over int8 planes.  A 64-byte LDS row then holds 64
+// channels instead of 32 and every address below is unchanged when counted in 2-byte units (the host
+// passes lda/2 and Kc/2); x = 128*hi + lo, the products hi*hi and hi*lo + lo*hi accumulate exactly
+// in two int32 sets (v_mfma_i32_32x32x32_i8, twice the bf16 rate) and are combined in the epilogue.
+template <int EPI, bool SPLIT, class C, bool I8 = false>
 __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg) {
+  static_assert(!I8 || (SPLIT && EPI == CUBE_EPI_GATE), "int8x2 is built for the gated convolutions only");
+  using acc_t = typename std::conditional<I8, i32x16, f32x16>::type;
+  using frag_t = typename std::conditional<I8, i32x4, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int NW = C::WM * C::WN;
@@ -223,13 +238,17 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_rd[j][ks] = lds_off(wc * (BN / C::WN) + j * 32 + l31, 2 * ks + lh);
 
-  f32x16 acc[TM][TN];
+  acc_t acc[TM][TN];
+  acc_t acc2[I8 ? TM : 1][TN];  // int8x2: the cross terms hi*lo + lo*hi
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0;
+        if constexpr (I8) acc2[i][j][r] = 0;
+      }
 
 #define ISSUE_A_PIECE(KC, BUF, I)                                                             \
   {                                                                                           \
@@ -282,14 +301,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
       aoff[i] = ok ? (kc & 1) * A_BUF + lds_off(row, lh) : ZERO_OFF;
       alo[i] = ok ? A_PLANE : 0;
     }
-    bf16x8 fb[2][NP][TN];
-    bf16x8 fa[2][NP];
+    frag_t fb[2][NP][TN];
+    frag_t fa[2][NP];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][0]);
-    fa[0][0] = *reinterpret_cast<const bf16x8*>(smem + aoff[0]);
-    if constexpr (SPLIT) fa[0][1] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + alo[0]);
+      for (int j = 0; j < TN; ++j) fb[0][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][0]);
+    fa[0][0] = *reinterpret_cast<const frag_t*>(smem + aoff[0]);
+    if constexpr (SPLIT) fa[0][1] = *reinterpret_cast<const frag_t*>(smem + aoff[0] + alo[0]);
 #pragma unroll
     for (int u = 0; u < 2 * TM; ++u) {
       const int ks = u / TM, i = u % TM;
@@ -297,23 +316,29 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         const int ks2 = (u + 1) / TM, i2 = (u + 1) % TM;
         // chunk = (2*ks + lh) ^ swz: the k-substep toggles bit 1 of the chunk index = offset ^ 32
         const int o = aoff[i2] ^ (ks2 ? 32 : 0);
-        fa[(u + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + o);
-        if constexpr (SPLIT) fa[(u + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + o + alo[i2]);
+        fa[(u + 1) & 1][0] = *reinterpret_cast<const frag_t*>(smem + o);
+        if constexpr (SPLIT) fa[(u + 1) & 1][1] = *reinterpret_cast<const frag_t*>(smem + o + alo[i2]);
         if (u + 1 == TM) {
 #pragma unroll
           for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              fb[1][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * B_PLANE + b_rd[j][1]);
+              fb[1][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][1]);
         }
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (SPLIT) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][1][j], acc[i][j], 0, 0, 0);
+        if constexpr (I8) {
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][1], fb[ks][0][j], acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][0], fb[ks][1][j], acc2[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
+        } else {
+          if constexpr (SPLIT) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][1][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
       }
       // DMA slots q of this unit: the weight pieces of step s+PD and the activation pieces of the
       // NEXT channel chunk.  The slab buffer of chunk kc+1 is free during all taps of chunk kc, so
@@ -376,7 +401,57 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     uint16_t* __restrict__ out0_lo = p.out0_lo;
     const bool ch_ok = ch < p.n_valid;
     const int res_mode = p.res_mode;
-    if (p.vec_out) {
+    if constexpr (I8) {
+      // int8x2 planes out: pre-activation = (128*hh + cross) * w_scale[col] + bias, the gate value g in
+      // (-1, 1) as q = round(g * CUBE_I8_ONE) = 128*hi + lo with hi in [-127, 127], lo in [-64, 63].
+      // 32x32 tiles transposed through wave-private LDS, 16 bytes (16 channels) per lane and plane.
+      constexpr int SROW8 = 48;
+      unsigned char* stg = smem + wid * (2 * 32 * SROW8);
+      unsigned char* out8 = reinterpret_cast<unsigned char*>(p.out0);
+      unsigned char* out8_lo = reinterpret_cast<unsigned char*>(p.out0_lo);
+      const float ws_a = p.w_scale[wcol0 + l31], ws_b = p.w_scale[wcol0 + 32 + l31];
+      const int srow = lane >> 1, schunk = lane & 1;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float ba[16], bb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (btab) {
+            const size_t o = tab_off(row);
+            ba[r] = btab[o];
+            bb[r] = btab[o + 32];
+          } else {
+            ba[r] = bias_a;
+            bb[r] = bias_b;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float ca = fmaf((float)acc[i][0][r], 128.f, (float)acc2[i][0][r]) * ws_a + ba[r];
+          const float cb = fmaf((float)acc[i][1][r], 128.f, (float)acc2[i][1][r]) * ws_b + bb[r];
+          const float g = tanhf_(ca) * sigmoidf_(cb);
+          int q = __float2int_rn(g * (float)CUBE_I8_ONE);
+          q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
+          const int h = (q + 64) >> 7;
+          stg[lr * SROW8 + l31] = (unsigned char)h;
+          stg[32 * SROW8 + lr * SROW8 + l31] = (unsigned char)(q - (h << 7));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cbase = wcol0 / 2 + schunk * 16;
+        const int row = orow_lds[wrow0 - m0 + i * 32 + srow];  // -1 = none
+        if (row >= 0 && cbase < p.n_valid) {
+          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes
+          *reinterpret_cast<uint4*>(out8 + o) = *reinterpret_cast<const uint4*>(stg + srow * SROW8 + schunk * 16);
+          *reinterpret_cast<uint4*>(out8_lo + o) = *reinterpret_cast<const uint4*>(stg + 32 * SROW8 + srow * SROW8 + schunk * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    } else if (p.vec_out) {
       // no residual stream (character CNN): transpose each 32x32 gate tile through wave-private LDS
       // (the operand images are dead after the last barrier) and store 16 bytes per lane, 64-byte
       // row segments, instead of 2-byte scattered stores.
@@ -506,17 +581,17 @@ inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR) {
 
 constexpr int NUM_CUS = 256;
 
-template <int EPI, bool SPLIT, class C>
+template <int EPI, bool SPLIT, class C, bool I8 = false>
 int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
   static CubeLdsReservation reserved;
-  if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C>, lds))
+  if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C, I8>, lds))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
   p.n_tiles = p.N / C::BN;
   p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR);
   if (p.m_tiles < 0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: a sequence group does not fit the activation slab");
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
-  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
   return CUBE_OK;
 }
 
@@ -554,18 +629,21 @@ int launch(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
-
-extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
+// both entry points: w_scale != NULL selects int8x2 operands
+int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
+  const bool i8 = w_scale != nullptr;
+  const int BKC = i8 ? 2 * BK : BK;  // channels per 64-byte LDS row
   if (!a) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null args");
   if (a->M <= 0) return CUBE_OK;
   if (!a->A || !a->W) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null operand");
   if ((a->A_lo == nullptr) != (a->W_lo == nullptr))
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: A_lo and W_lo must be given together (bf16x3) or not at all (bf16)");
   if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: taps=%d", a->taps);
-  if (a->Kc <= 0 || a->Kc % BK) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BK);
+  if (a->Kc <= 0 || a->Kc % BKC) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BKC);
   if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of 128", a->N);
-  if (a->lda < a->Kc || a->lda % 8) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
+  if (a->lda < a->Kc || a->lda % (i8 ? 16 : 8)) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
+  if (i8 && (a->epilogue != CUBE_EPI_GATE || !a->A_lo || !a->W_lo || a->res || a->out1 || a->out2 || !a->out0 || !a->out0_lo))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: int8x2 needs both planes of A, W and out0, the gate epilogue and no residual stream");
   if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->A_lo) || !aligned16(a->W_lo))
     CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: operands must be 16-byte aligned");
   ConvGroups cg;
@@ -591,8 +669,10 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab and row_group go together");
   if (a->bias_tab && (a->epilogue != CUBE_EPI_GATE || a->taps > 5 || a->n_groups <= 0))
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab needs the gate epilogue, taps <= 5 and n_groups > 0");
-  p.A = (const uint16_t*)a->A; p.A_lo = (const uint16_t*)a->A_lo; p.lda = a->lda; p.M = a->M; p.seq_len = seq;
-  p.taps = a->taps; p.Kc = a->Kc;
+  p.w_scale = w_scale;
+  // int8 planes: the kernel counts in 2-byte units (its addressing is then the bf16 one, byte for byte)
+  p.A = (const uint16_t*)a->A; p.A_lo = (const uint16_t*)a->A_lo; p.lda = i8 ? a->lda / 2 : a->lda; p.M = a->M; p.seq_len = seq;
+  p.taps = a->taps; p.Kc = i8 ? a->Kc / 2 : a->Kc;
   p.W = (const uint16_t*)a->W; p.W_lo = (const uint16_t*)a->W_lo; p.N = a->N; p.bias = a->bias;
   p.n_valid = a->n_valid > 0 ? a->n_valid : (a->epilogue == CUBE_EPI_GATE ? a->N / 2 : a->N);
   p.accumulate = a->accumulate;
@@ -631,6 +711,12 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
       if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
       p.vec_out = !a->res && a->out0 && half % 8 == 0 && a->ldo0 % 8 == 0 && a->col0 % 8 == 0 && aligned16(a->out0) &&
                   aligned16(a->out0_lo);
+      if (i8) {
+        if (half % 16 || a->ldo0 % 16 || a->col0 % 16 || !aligned16(a->out0) || !aligned16(a->out0_lo))
+          CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: out0 planes need 16-byte aligned rows (half, ldo0, col0 multiples of 16)");
+        rc = launch_cfg<CUBE_EPI_GATE, true, CfgI8, true>(p, cg, st);
+        break;
+      }
       rc = launch<CUBE_EPI_GATE>(p, cg, st);
       break;
     }
@@ -640,4 +726,13 @@ extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
   if (rc != CUBE_OK) return rc;
   CUBE_CHECK_LAUNCH("cube_gemm_bf16");
   return CUBE_OK;
+}
+
+}  // namespace
+
+extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) { return gemm_entry(a, nullptr, stream); }
+
+extern "C" int cube_gemm_i8x2(const cube_gemm_args* a, const float* w_scale, void* stream) {
+  if (!w_scale) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: null w_scale");
+  return gemm_entry(a, w_scale, stream);
 }

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 7; }
+extern "C" int cube_abi_version(void) { return 8; }
 
 namespace {
 
@@ -148,6 +148,70 @@ __global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int
         make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
 }
 
+// int8x2 layers (cube_hip.h): 16 channels (16 bytes per plane) per thread; the sum over the positions
+// of a word is exact in int32
+__global__ __launch_bounds__(256) void masked_mean_i8_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
+                                                             int C, uint16_t* out, uint16_t* out_lo, int ld_out,
+                                                             const int32_t* word_rows) {
+  const int nchunk = C >> 4;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * nchunk) return;
+  const int n = t / nchunk, c = (t - n * nchunk) << 4;
+  const int l = min(max(len[n], 0), W);
+  const float den = (float)max(len[n], 1);
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  for (int k = 0; k < ly.n; ++k) {
+    const size_t base = (size_t)(word_rows ? word_rows[(size_t)k * N + n] : n * W) * ld_x + c;  // bytes
+    const unsigned char* hi = reinterpret_cast<const unsigned char*>(ly.hi[k]) + base;
+    const unsigned char* lo = reinterpret_cast<const unsigned char*>(ly.lo[k]) + base;
+    int sk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sk[j] = 0;
+    for (int q0 = 0; q0 < l; q0 += 4) {
+      uint4 v[4], u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = min(q0 + i, l - 1);
+        v[i] = *reinterpret_cast<const uint4*>(hi + (size_t)q * ld_x);
+        u[i] = *reinterpret_cast<const uint4*>(lo + (size_t)q * ld_x);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (q0 + i >= l) break;
+        const uint32_t wh[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        const uint32_t wl[4] = {u[i].x, u[i].y, u[i].z, u[i].w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int hq = (int)(int8_t)(wh[j >> 2] >> (8 * (j & 3)));
+          const int lq = (int)(int8_t)(wl[j >> 2] >> (8 * (j & 3)));
+          sk[j] += (hq << 7) + lq;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] += ly.weight[k] * ((float)sk[j] * (1.0f / (float)CUBE_I8_ONE));
+  }
+  uint16_t h[16], lw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float v = s[j] / den;
+    if (out_lo) split_bf16(v, h[j], lw[j]); else h[j] = f32_to_bf16(v);
+  }
+  const size_t o = (size_t)n * ld_out + c;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const uint16_t* hh = h + 8 * half;
+    const uint16_t* ll = lw + 8 * half;
+    *reinterpret_cast<uint4*>(out + o + 8 * half) =
+        make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
+    if (out_lo)
+      *reinterpret_cast<uint4*>(out_lo + o + 8 * half) =
+          make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
+  }
+}
+
 __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K,
                                                          uint16_t* da, uint16_t* da_lo, int ld_a, int col_a,
                                                          uint16_t* db, uint16_t* db_lo, int ld_b, int col_b) {
@@ -166,6 +230,7 @@ __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int l
 }
 
 // ---- first gated character layer as table look-ups (see cube_char_conv0_lookup in the header)
+template <bool I8>
 __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restrict__ T, const float* __restrict__ btab,
                                                            const int32_t* __restrict__ cc, const int32_t* __restrict__ lang_word,
                                                            const cube_conv_groups cg, int taps, int half, int n_combo,
@@ -215,6 +280,21 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   const float4 bb = *reinterpret_cast<const float4*>(bp + half);
   const float gv[4] = {tanhf_(a.x + ba.x) * sigmoidf_(b.x + bb.x), tanhf_(a.y + ba.y) * sigmoidf_(b.y + bb.y),
                        tanhf_(a.z + ba.z) * sigmoidf_(b.z + bb.z), tanhf_(a.w + ba.w) * sigmoidf_(b.w + bb.w)};
+  if constexpr (I8) {  // int8x2 planes (cube_hip.h): q = round(g * CUBE_I8_ONE) = 128*hi + lo
+    uint32_t ph = 0, pl = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int q = __float2int_rn(gv[k] * (float)CUBE_I8_ONE);
+      q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
+      const int hq = (q + 64) >> 7;
+      ph |= (uint32_t)(hq & 0xff) << (8 * k);
+      pl |= (uint32_t)((q - (hq << 7)) & 0xff) << (8 * k);
+    }
+    const size_t ob = (size_t)row * ld_out + c4;  // bytes
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + ob) = ph;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out_lo) + ob) = pl;
+    return;
+  }
   uint16_t h[4], l[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -271,9 +351,9 @@ extern "C" int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, i
   return CUBE_OK;
 }
 
-extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
-                                int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
-                                const int32_t* word_rows, void* stream) {
+static int masked_mean_entry(bool i8, const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                             int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
+                             const int32_t* word_rows, void* stream) {
   if (N <= 0) return CUBE_OK;
   if (!x_hi || !len || !out || W <= 0 || C <= 0 || C > ld_x || C > ld_out) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: bad args");
   if (n_layers <= 0 || n_layers > CUBE_MAX_MEAN_LAYERS) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean: n_layers=%d (max %d)", n_layers, CUBE_MAX_MEAN_LAYERS);
@@ -287,7 +367,12 @@ extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo
   }
   bool vec = C % 8 == 0 && ld_x % 8 == 0 && ld_out % 8 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)out_lo % 16 == 0;
   for (int k = 0; k < n_layers; ++k) vec = vec && (uintptr_t)ly.hi[k] % 16 == 0 && (uintptr_t)ly.lo[k] % 16 == 0;
-  if (vec)
+  if (i8) {
+    if (!x_lo || !vec || C % 16 || ld_x % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_masked_mean_i8: both planes, C and ld_x multiples of 16, 16-byte aligned pointers");
+    for (int k = 0; k < n_layers; ++k) if (!ly.lo[k]) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean_i8: null lo plane %d", k);
+    hipLaunchKernelGGL(masked_mean_i8_kernel, dim3((N * (C / 16) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
+                       len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
+  } else if (vec)
     hipLaunchKernelGGL(masked_mean_vec_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
                        len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
   else
@@ -295,6 +380,17 @@ extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo
                        (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
   CUBE_CHECK_LAUNCH("cube_masked_mean");
   return CUBE_OK;
+}
+
+extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                                int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
+                                const int32_t* word_rows, void* stream) {
+  return masked_mean_entry(false, x_hi, x_lo, weight, n_layers, ld_x, len, N, W, C, out, out_lo, ld_out, word_rows, stream);
+}
+extern "C" int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
+                                   int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
+                                   const int32_t* word_rows, void* stream) {
+  return masked_mean_entry(true, x_hi, x_lo, weight, n_layers, ld_x, len, N, W, C, out, out_lo, ld_out, word_rows, stream);
 }
 
 extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, void* dst_a, void* dst_a_lo,
@@ -310,9 +406,10 @@ extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int r
   return CUBE_OK;
 }
 
-extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                                      const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
-                                      void* out_lo, int ld_out, void* stream) {
+static int conv0_lookup_entry(bool i8, const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                              const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                              void* out_lo, int ld_out, void* stream) {
+  if (i8 && !out_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup_i8: needs both planes");
   if (!T || !btab || !cc || !lang_word || !groups || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: null pointer");
   if ((taps != 1 && taps != 3 && taps != 5) || half <= 0 || half % 4 || half > 1024 || n_combo <= 0 || ld_out < half || ld_out % 4)
     CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: bad taps / half / ld_out");
@@ -330,10 +427,25 @@ extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const i
   const int tpr = half / 4;
   const int rpb = tpr >= 256 ? 1 : 256 / tpr;
   if (tpr > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: half=%d too wide", half);
-  hipLaunchKernelGGL(conv0_lookup_kernel, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
-                     lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
+  if (i8)
+    hipLaunchKernelGGL(conv0_lookup_kernel<true>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
+                       lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
+  else
+    hipLaunchKernelGGL(conv0_lookup_kernel<false>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
+                       lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
   CUBE_CHECK_LAUNCH("cube_char_conv0_lookup");
   return CUBE_OK;
+}
+
+extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                                      const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                                      void* out_lo, int ld_out, void* stream) {
+  return conv0_lookup_entry(false, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
+}
+extern "C" int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
+                                         const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                                         void* out_lo, int ld_out, void* stream) {
+  return conv0_lookup_entry(true, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
 }
 
 extern "C" int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream) {

@@ -10,12 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 7  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 8  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
 
 MAX_CONV_GROUPS = 32
+I8_ONE = 16256  # CUBE_I8_ONE: int8x2 fixed point, x = (128*hi + lo) / I8_ONE
 
 
 class ConvGroups(ctypes.Structure):
@@ -84,12 +85,17 @@ SIGNATURES = {
     "cube_last_error": (ctypes.c_char_p, []),
     "cube_abi_version": (c_int, []),
     "cube_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    "cube_gemm_i8x2": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_void_p]),
     "cube_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),
     "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,
                                        c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "cube_masked_mean_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_void_p]),
+    "cube_char_conv0_lookup_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,
+                                          c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -163,9 +169,10 @@ def _planes(x, col=0):
 
 def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
          rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
-         a_col=0, bias_tab=None, row_group=None, groups=None, stream=None):
+         a_col=0, bias_tab=None, row_group=None, groups=None, stream=None, w_scale=None):
     """A, W, out0 (bf16 epilogues), out1, out2: `Pair`s; out0 of CUBE_EPI_F32: an fp32 tensor.
-    bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements)."""
+    bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements).
+    w_scale (f32 [N]): A, W and out0 are int8x2 planes (cube_gemm_i8x2; lda, Kc, ldo0 in int8 elements)."""
     a = GemmArgs()
     a.A, a.A_lo = _planes(A, a_col)
     a.W, a.W_lo = _planes(W)
@@ -189,15 +196,23 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     a.n_groups = 0 if bias_tab is None else bias_tab.shape[0]
     if groups is not None:
         a.groups = ctypes.pointer(groups)
+    if w_scale is not None:
+        if a_col or col0:
+            raise ValueError("int8x2 operands start at column 0")
+        check(load().cube_gemm_i8x2(ctypes.byref(a), w_scale.data_ptr(), stream if stream is not None else stream_handle()),
+              "cube_gemm_i8x2")
+        return
     check(load().cube_gemm_bf16(ctypes.byref(a), stream if stream is not None else stream_handle()), "cube_gemm_bf16")
 
 
-def masked_mean(layers, weights, ld_x, word_len, N, W, C, out, ld_out, word_rows=None, stream=None):
-    """layers: list of Pair [N*W, ld_x] (or ragged, with word_rows i32 [n_layers, N]); out: Pair [N, ld_out]."""
+def masked_mean(layers, weights, ld_x, word_len, N, W, C, out, ld_out, word_rows=None, stream=None, i8=False):
+    """layers: list of Pair [N*W, ld_x] (or ragged, with word_rows i32 [n_layers, N]); out: Pair [N, ld_out].
+    i8: the layers are int8x2 planes (ld_x in int8 elements)."""
     n = len(layers)
     his = (c_void_p * n)(*[l.hi.data_ptr() for l in layers])
     los = (c_void_p * n)(*[l.lo.data_ptr() for l in layers]) if layers[0].lo is not None else None
     ws = (ctypes.c_float * n)(*weights)
-    check(load().cube_masked_mean(his, los, ws, n, ld_x, word_len.data_ptr(), N, W, C, out.hi.data_ptr(), ptr(out.lo),
-                                  ld_out, ptr(word_rows), stream if stream is not None else stream_handle()),
+    fn = load().cube_masked_mean_i8 if i8 else load().cube_masked_mean
+    check(fn(his, los, ws, n, ld_x, word_len.data_ptr(), N, W, C, out.hi.data_ptr(), ptr(out.lo),
+             ld_out, ptr(word_rows), stream if stream is not None else stream_handle()),
           "cube_masked_mean")

@@ -49,7 +49,7 @@ def gate_column_order(half):
     return order
 
 
-def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None):
+def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False):
     """-> dict(W bf16 [N, taps*Kc], bias f32 [N], Kc, N, half).
     in_perm: for each column of the HIP activation buffer, the reference input channel (or -1).
     bcast = (reference channels, table [G, len(channels)]): input channels that carry the same
@@ -57,7 +57,9 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None):
     concatenates before each conv).  They are left out of the GEMM; their contribution goes into
     `bias_tab` f32 [G, 32, N]: entry [g, m] = bias + sum over the taps t in bit mask m of
     W[:, channels, t] @ table[g]  (m = the taps that fall inside the sequence at a position).
-    `bias_tab_q` is the same from bf16-rounded weights and table (single-pass "bf16" contract)."""
+    `bias_tab_q` is the same from bf16-rounded weights and table (single-pass "bf16" contract).
+    int8: also `W8` (Pair of int8 planes [N, taps*Kc], 64-channel chunks) and `w_scale` f32 [N] for
+    cube_gemm_i8x2: w[n, :] = (128*hi + lo) * max|w[n, :]| / I8_ONE (include/cube_hip.h)."""
     w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
     b = sd[prefix + ".0.conv.bias"].float()
     s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
@@ -83,9 +85,23 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None):
     tmp[:, :, valid_k] = sub.permute(0, 2, 1)
     W[valid_n] = tmp
     bias[valid_n] = b[src_n]
+    q8 = None
+    if int8 and Kc % 64 == 0:
+        from cube_amd.hip import I8_ONE, Pair
+        wmax = W.abs().amax(dim=(1, 2)).double().clamp(min=1e-30)
+        q = torch.round(W.double() / wmax[:, None, None] * I8_ONE).to(torch.int32)
+        hi = (q + 64) >> 7  # arithmetic shift = floor: hi in [-127, 127], lo in [-64, 63]
+        lo = q - (hi << 7)
+        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -64 and int(lo.max()) <= 63
+
+        def chunks(t):
+            return t.view(N, taps, Kc // 64, 64).permute(0, 2, 1, 3).reshape(N, taps * Kc).to(torch.int8).contiguous()
+        q8 = dict(W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * 128.0 / (I8_ONE * I8_ONE)).float().contiguous())
     # K order of cube_gemm_bf16: 32-channel chunk outer, tap inner
     W = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)
     out = dict(W=_bf16(W), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
+    if q8 is not None:
+        out.update(q8)
     if bcast is not None:
         chans, table = bcast
         chans = torch.as_tensor(np.asarray(chans), dtype=torch.long)
@@ -210,7 +226,7 @@ def pack_wordgram(sd, prefix, n_layers, char_emb, case_emb, lang, half):
         cin = char_emb + case_emb if l == 0 else half  # then come the lang channels
         pk["char_convs"].append(pack_gated_conv(sd, "%s._convolutions_char.%d" % (prefix, l), np.arange(cin),
                                                 double_first=half if l > 0 else 0,
-                                                bcast=(cin + np.arange(lang), wn_lang)))
+                                                bcast=(cin + np.arange(lang), wn_lang), int8=l > 0))
     pk["char_l0"] = pack_conv0_tables(sd, prefix + "._convolutions_char.0", sd[prefix + "._tok_emb.weight"],
                                       sd[prefix + "._case_emb.weight"], wn_lang)
     pk["char_pre_out"] = pack_linear(sd[prefix + "._pre_out.linear_layer.weight"], sd[prefix + "._pre_out.linear_layer.bias"])

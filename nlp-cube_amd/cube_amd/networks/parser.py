@@ -17,6 +17,7 @@ mid-batch syncs (parser.py:125, 425, 428-431) are gone because unpack, soft-max,
 and the head gather for label scoring all stay on the device.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -84,6 +85,9 @@ class _HipNet:
         self._buf = None
         self.training = False
         self.precision = "bf16x3"  # or "bf16"; set before .to(device)
+        # character-CNN layers >= 1 in int8x2 fixed point (cube_gemm_i8x2; bf16x3 mode only): their inputs
+        # are gate outputs, |x| < 1.  CUBE_CHAR_I8=0/1 overrides.
+        self.char_int8 = os.environ.get("CUBE_CHAR_I8", "0") == "1"
         self._timing = None
         self._streams = None
         self._layouts = {}
@@ -274,6 +278,9 @@ class _HipNet:
         rows = bt["char_rows"]
         l0 = pk.get("char_l0")
         nchar = len(pk["char_convs"])
+        # int8x2 planes for the gate outputs when every GEMM layer reads one (layer 0 = table look-ups)
+        i8 = (self.char_int8 and self._split and l0 is not None and lay.xc_w % 64 == 0 and ch % 16 == 0 and
+              all("W8" in cv for cv in pk["char_convs"][1:]))
         if l0 is None:
             xc0 = buf.get("xc0", rows[0], lay.xc0_w)
             gather(xc0, lay.xc0_w, 0, lay.char_emb, pk["tok_emb"], bt["char_idx"], None, rows[0])
@@ -281,18 +288,30 @@ class _HipNet:
         # every gated layer keeps its own output g_l: the next layer reads it, and the masked mean
         # sums them (no fp32 residual stream through HBM at N*W rows).  The language channels are
         # not materialised: they enter through the per-(language, tap mask) bias table.
-        gl = [buf.get("xc_g%d" % l, rows[l + 1], lay.xc_w) for l in range(nchar)]
+        if i8:  # int8 [rows, xc_w] per plane = the bytes of a bf16 buffer of half the width
+            gl = [buf.get("xc_q%d" % l, rows[l + 1], lay.xc_w // 2) for l in range(nchar)]
+        else:
+            gl = [buf.get("xc_g%d" % l, rows[l + 1], lay.xc_w) for l in range(nchar)]
         src, src_ld = (xc0, lay.xc0_w) if l0 is None else (None, 0)
         for l, cv in enumerate(pk["char_convs"]):
             if l == 0 and l0 is not None:
                 # embeddings + first gated layer as table look-ups (cube_char_conv0_lookup): HBM/L2-bound
                 # instead of a K = 5*288 GEMM over every character position
                 with self._timed("char_conv0"):
-                    hip.check(lib.cube_char_conv0_lookup(l0["T"].data_ptr(), l0["btab"].data_ptr(), bt["char_idx"].data_ptr(),
-                                                         bt["lang_word"].data_ptr(), ctypes.pointer(bt["conv_groups"][0]),
-                                                         l0["taps"], l0["half"], l0["n_combo"], gl[0].hi.data_ptr(),
-                                                         lo(gl[0].lo), lay.xc_w, st), "cube_char_conv0_lookup")
+                    fn = lib.cube_char_conv0_lookup_i8 if i8 else lib.cube_char_conv0_lookup
+                    hip.check(fn(l0["T"].data_ptr(), l0["btab"].data_ptr(), bt["char_idx"].data_ptr(),
+                                 bt["lang_word"].data_ptr(), ctypes.pointer(bt["conv_groups"][0]),
+                                 l0["taps"], l0["half"], l0["n_combo"], gl[0].hi.data_ptr(),
+                                 lo(gl[0].lo), lay.xc_w, st), "cube_char_conv0_lookup")
                 src, src_ld = gl[0], lay.xc_w
+                continue
+            if i8:
+                with self._timed("char_conv"):
+                    hip.gemm(src, src_ld, rows[l], cv["Kc"], cv["W8"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
+                             ldo0=lay.xc_w, col0=0, taps=cv["taps"], seq_len=W, n_valid=cv["half"],
+                             bias_tab=cv["bias_tab"], row_group=bt["lang_word"], groups=bt["conv_groups"][l], stream=st,
+                             w_scale=cv["w_scale"])
+                src, src_ld = gl[l], lay.xc_w
                 continue
             with self._timed("char_conv" if l > 0 else "char_conv0"):
                 hip.gemm(src, src_ld, rows[l], cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=gl[l],
@@ -302,7 +321,7 @@ class _HipNet:
         pool_w = p32(ch)
         pool = buf.get("pool", N, pool_w)
         hip.masked_mean(gl, [1.0] * (nchar - 1) + [2.0], lay.xc_w, bt["word_len"], N, W, ch, pool, pool_w,
-                        word_rows=bt["word_rows"], stream=st)
+                        word_rows=bt["word_rows"], stream=st, i8=i8)
         return pool, pool_w
 
     def _trunk(self, bt, final, final_w, lang_dsts, tap=None, tap_w=0, ext_b=None, ext_b_w=0, ext_b_col=0,

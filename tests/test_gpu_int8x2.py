@@ -1,0 +1,155 @@
+"""int8x2 fixed-point path of the character CNN (cube_gemm_i8x2, cube_char_conv0_lookup_i8,
+cube_masked_mean_i8; include/cube_hip.h) through the C ABI.
+
+* the GEMM against torch.conv1d in float64 on the SAME quantised operands (what remains is the dropped
+  lo*lo term, 2^-14 relative, and the 6.2e-5 output step);
+* the whole parser with `char_int8` on against the REFERENCE's own outputs (tests/golden), to the same
+  bar as the default mode (scores 1e-3 relative, decisions >= 99.9 %).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "nlp-cube_amd")]
+from tests import cases  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+def _planes(x):
+    """float tensor in [-1, 1] -> (q int32, hi int8, lo int8), q = round(x * I8_ONE) = 128*hi + lo."""
+    from cube_amd.hip import I8_ONE
+    q = torch.round(x.double() * I8_ONE).to(torch.int32).clamp(-I8_ONE, I8_ONE)
+    hi = (q + 64) >> 7
+    lo = q - (hi << 7)
+    return q, hi.to(torch.int8), lo.to(torch.int8)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_gemm_i8x2_ragged_groups_and_bias_table(dev, big):
+    from cube_amd import hip
+    from cube_amd.networks import packing
+    g = torch.Generator().manual_seed(11)
+    Kc, nb, half, n_lang = 128, 16, 256 if big else 48, 4
+    spec = [(3, 1, 1), (5, 3, 1), (900 if big else 7, 7, 5), (5000 if big else 9, 14, 14), (4, 9, 8)]
+    w = torch.randn((2 * half, Kc + nb, 5), generator=g) / np.sqrt(5 * (Kc + nb))
+    sd = {"c.0.conv.weight": w, "c.0.conv.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.weight": torch.rand(2 * half, generator=g) + 0.5, "c.1.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.running_mean": torch.randn(2 * half, generator=g) * 0.1, "c.1.running_var": torch.rand(2 * half, generator=g) + 0.5}
+    table = torch.randn((n_lang, nb), generator=g)
+    pk = packing.pack_gated_conv(sd, "c", np.arange(Kc), bcast=(Kc + np.arange(nb), table), int8=True)
+    # the weights the kernel sees, back in reference channel order: un-chunk, un-permute the columns
+    N = pk["N"]
+    w8 = (pk["W8"].hi.to(torch.int32) * 128 + pk["W8"].lo.to(torch.int32)).double()
+    w8 = w8.view(N, Kc // 64, 5, 64).permute(0, 2, 1, 3).reshape(N, 5, Kc)
+    wq = w8 * (pk["w_scale"].double() * hip.I8_ONE / 128.0)[:, None, None]          # [N, taps, Kc] dequantised
+    order = packing.gate_column_order(half)
+    wref = torch.zeros((2 * half, Kc, 5), dtype=torch.float64)
+    wref[torch.from_numpy(order[order >= 0])] = wq[torch.from_numpy(np.where(order >= 0)[0])].permute(0, 2, 1)
+    s = sd["c.1.weight"] / torch.sqrt(sd["c.1.running_var"] + 1e-5)
+    wf = (w * s[:, None, None]).double()
+    assert float((wref - wf[:, :Kc]).abs().max() / wf.abs().max()) < 1e-4  # 15-bit weights
+    bf = (sd["c.0.conv.bias"] - sd["c.1.running_mean"]) * s + sd["c.1.bias"]
+    cg = hip.ConvGroups()
+    cg.n = len(spec)
+    rin = rout = wd = 0
+    for k, (nw, si, so) in enumerate(spec):
+        cg.row0_in[k], cg.n_rows[k], cg.seq_in[k], cg.row0_out[k], cg.seq_out[k], cg.word0[k] = rin, nw * si, si, rout, so, wd
+        rin, rout, wd = rin + nw * si, rout + nw * so, wd + nw
+    A = torch.rand((rin, Kc), generator=g) * 2 - 1
+    A[0, :4] = torch.tensor([1.0, -1.0, 0.0, 0.99999])
+    q, ahi, alo = _planes(A)
+    Aq = q.double() / hip.I8_ONE
+    lang = torch.randint(0, n_lang, (wd,), generator=g)
+    exp = torch.zeros((rout, half), dtype=torch.float64)
+    wfull = torch.cat([wref, wf[:, Kc:]], 1)
+    for k, (nw, si, so) in enumerate(spec):
+        a = Aq[cg.row0_in[k]:cg.row0_in[k] + nw * si].view(nw, si, Kc)
+        lg = table[lang[cg.word0[k]:cg.word0[k] + nw]].double()[:, None, :].expand(nw, si, nb)
+        co = torch.nn.functional.conv1d(torch.cat([a, lg], -1).permute(0, 2, 1), wfull, bf.double(), padding=2)
+        gate = (torch.tanh(co[:, :half]) * torch.sigmoid(co[:, half:])).permute(0, 2, 1)[:, :so, :]
+        exp[cg.row0_out[k]:cg.row0_out[k] + nw * so] = gate.reshape(nw * so, half)
+    ld = (half + 63) // 64 * 64 + 16
+    out = hip.Pair(torch.full((rout + 3, ld), 7, dtype=torch.int8, device=dev),
+                   torch.full((rout + 3, ld), 7, dtype=torch.int8, device=dev))
+    hip.gemm(hip.Pair(ahi.to(dev), alo.to(dev)), Kc, rin, pk["Kc"], packing.to_device(pk["W8"], dev), pk["N"],
+             pk["bias"].to(dev), hip.EPI_GATE, out0=out, ldo0=ld, col0=0, taps=5, seq_len=14, n_valid=half,
+             bias_tab=pk["bias_tab"].to(dev), row_group=lang.to(torch.int32).to(dev), groups=cg,
+             w_scale=pk["w_scale"].to(dev))
+    torch.cuda.synchronize()
+    hi, lo = out.hi.cpu().to(torch.int32), out.lo.cpu().to(torch.int32)
+    assert int(hi[:rout, :half].abs().max()) <= 127 and int(lo[:rout, :half].min()) >= -64 and int(lo[:rout, :half].max()) <= 63
+    got = (hi * 128 + lo).double() / hip.I8_ONE
+    np.testing.assert_allclose(got[:rout, :half].numpy(), exp.numpy(), rtol=0, atol=1.5e-4)
+    assert (hi[rout:] == 7).all() and (lo[rout:] == 7).all() and (hi[:, (half + 15) // 16 * 16:] == 7).all()  # untouched
+
+
+def test_gemm_i8x2_rejects_what_it_does_not_support(dev):
+    from cube_amd import hip
+    z = torch.zeros((64, 64), dtype=torch.int8, device=dev)
+    w = hip.Pair(torch.zeros((128, 64), dtype=torch.int8, device=dev), torch.zeros((128, 64), dtype=torch.int8, device=dev))
+    ws = torch.ones(128, device=dev)
+    bias = torch.zeros(128, device=dev)
+    out = hip.Pair(torch.zeros((64, 64), dtype=torch.int8, device=dev), torch.zeros((64, 64), dtype=torch.int8, device=dev))
+    with pytest.raises(hip.CubeHipError):  # Kc must be a multiple of 64
+        hip.gemm(hip.Pair(z, z), 64, 64, 32, w, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws)
+    with pytest.raises(hip.CubeHipError):  # gate epilogue only
+        hip.gemm(hip.Pair(z, z), 64, 64, 64, w, 128, bias, hip.EPI_BF16, out0=out, ldo0=64, n_valid=64, w_scale=ws)
+    with pytest.raises(hip.CubeHipError):  # no residual stream
+        hip.gemm(hip.Pair(z, z), 64, 64, 64, w, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws,
+                 res=torch.zeros((64, 64), device=dev), ld_res=64)
+
+
+_CASES = [(cases.FULL, "full_8x32", "g3_forward_full.npz"), (cases.FULL, "full_2x128", "g3_forward_full.npz"),
+          (cases.FULL, "ragged", "g3_forward_full.npz")]
+
+
+@pytest.mark.parametrize("case,doc_key,fixture", _CASES)
+def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixture):
+    """`Parser.char_int8` against the reference's own outputs, to the bar of the default mode."""
+    from cube_amd.networks.parser import Parser
+    from cube_amd.networks.utils import MorphoCollate
+    from tests.test_gpu_parity import REL_TOL, _margin_ok, _rel
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.char_int8 = True
+    p.load_state_dict(sd)
+    p.to(dev)
+    doc = cases.document(case, enc, doc_key)
+    X = MorphoCollate(enc).collate_fn(doc.sentences)
+    X.pop("y_upos")
+    r = p.decode_batch(X)
+    torch.cuda.synchronize()
+    assert "xc_q1" in p._buf._b, "the int8x2 path did not run"
+    g = np.load(os.path.join(golden_dir, fixture))
+    sl = r["bt"]["lens"].cpu().numpy()
+    arc, ref_arc = r["arc_logits"].cpu().numpy(), g["%s/arc_logits" % doc_key]
+    assert _rel(arc, ref_arc) < REL_TOL, _rel(arc, ref_arc)
+    assert _rel(r["upos_logits"].cpu().numpy(), g["%s/upos" % doc_key]) < REL_TOL
+    mask = np.arange(arc.shape[1])[None, :] < sl[:, None]
+    got_upos, ref_upos = r["upos"].cpu().numpy(), np.argmax(g["%s/upos" % doc_key], axis=-1)
+    nbad, agree = _margin_ok(g["%s/upos" % doc_key][mask], got_upos[mask], ref_upos[mask],
+                             REL_TOL * np.abs(g["%s/upos" % doc_key]).max())
+    assert nbad == 0 and agree >= 0.999, (nbad, agree)
+    heads, ref_heads = r["heads"].cpu().numpy(), g["%s/heads" % doc_key]
+    assert (r["status"].cpu().numpy() == 0).all()
+    assert (heads[mask] == ref_heads[mask]).mean() >= 0.999
+    same = mask & (heads == ref_heads)
+    lab, ref_lab = r["label_logits"].cpu().numpy(), g["%s/label_logits" % doc_key]
+    assert _rel(lab[same], ref_lab[same]) < REL_TOL, _rel(lab[same], ref_lab[same])
+    nbad, agree = _margin_ok(ref_lab[same], r["labels"].cpu().numpy()[same], np.argmax(ref_lab, -1)[same],
+                             REL_TOL * np.abs(ref_lab).max())
+    assert nbad == 0 and agree >= 0.999, (nbad, agree)
+    print("int8x2 %s: arc %.2e upos %.2e label %.2e" % (doc_key, _rel(arc, ref_arc),
+          _rel(r["upos_logits"].cpu().numpy(), g["%s/upos" % doc_key]), _rel(lab[same], ref_lab[same])))
