@@ -36,6 +36,7 @@ CONFIGS = {1: dict(B=256, L=32, name="en parser+tagger B=256 x L=32 (BASELINE co
            3: dict(B=None, L=None, n_sent=4096, name="ragged corpus L~clip(N(22,10),3,80), bucketed <=8192 tokens "
                                                         "(SURVEY 8d config 3, 4096-sentence sample per rank)")}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+I8_DENSE_PEAK_TOPS = 5000.0      # same table: I8 32x32x32 = 2x BF16 per clock
 
 
 def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300,)):
@@ -183,17 +184,23 @@ def main():
     # executed by this implementation: ragged rows, language channels folded into the bias table, 3 bf16 passes
     rows_exec = float(np.mean(bt["char_rows"][2:]))  # output rows of layers >= 1 (tiles run over output rows)
     passes = 3 if p.precision == "bf16x3" else 1
+    # int8x2 fixed point (Parser.char_int8, the default): three int8 slice products per channel pair
+    i8 = "xc_q1" in p._buf._b
+    peak = I8_DENSE_PEAK_TOPS if i8 else BF16_DENSE_PEAK_TFLOPS
     flops_executed = 2.0 * rows_exec * 5 * lay.char_half * nf * passes
     ms = kt["ms_mean"]
     achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms else 0.0
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "r1_traffic_i8.json" if i8 else "r1_traffic.json")
     if args.config == 1 and world == 1 and os.path.exists(tf):  # PMC pass of this workload, see the file
         with open(tf) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
-    roofline = dict(bound="mfma", achieved=achieved, peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / BF16_DENSE_PEAK_TFLOPS, traffic=traffic,
-                    kernel="gemm_kernel<GATE> (char conv, layers>=1)", launches=kt["n"], ms_per_launch=ms,
+    roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
+                    frac=achieved / peak, traffic=traffic, kernel_dtype="int8x2 (i32 accumulate)" if i8 else p.precision,
+                    peak_is="dense int8 MFMA (2x bf16)" if i8 else "dense bf16 MFMA",
+                    frac_of_bf16_peak=achieved / BF16_DENSE_PEAK_TFLOPS,
+                    kernel="gemm_kernel<GATE%s> (char conv, layers>=1)" % (", CfgI8, int8x2" if i8 else ""),
+                    launches=kt["n"], ms_per_launch=ms,
                     flops_per_launch=flops_per_launch, padded_W=bt["W"], rows_algorithmic=NW, rows_executed=rows_exec,
                     mfma_flops_executed_per_launch=flops_executed,
                     mfma_executed_tflops=flops_executed / (ms * 1e-3) / 1e12 if ms else 0.0,
@@ -201,7 +208,8 @@ def main():
     out = {
         "metric": "sentences/sec (node) parser+tagger inference", "value": sent_per_s, "unit": "sentences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": p.precision,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": p.precision + ("+int8x2" if i8 else ""),
         "data": "synthetic (SURVEY.md 8d: random-init weights seed 1234, synthetic vocabulary and sentences)",
         "config": {"workload": c["name"], "B": c["B"], "L": c["L"], "padded_W": bt["W"], "ext_emb": list(ext),
                    "sharding": "sentences sharded across ranks, no collective on the data path"},

@@ -86,8 +86,8 @@ class _HipNet:
         self.training = False
         self.precision = "bf16x3"  # or "bf16"; set before .to(device)
         # character-CNN layers >= 1 in int8x2 fixed point (cube_gemm_i8x2; bf16x3 mode only): their inputs
-        # are gate outputs, |x| < 1.  CUBE_CHAR_I8=0/1 overrides.
-        self.char_int8 = os.environ.get("CUBE_CHAR_I8", "0") == "1"
+        # are gate outputs, |x| < 1.  False = bf16x3 there too; CUBE_CHAR_I8=0 does the same.
+        self.char_int8 = os.environ.get("CUBE_CHAR_I8", "1") != "0"
         self._timing = None
         self._streams = None
         self._layouts = {}

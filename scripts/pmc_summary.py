@@ -1,9 +1,14 @@
 """Mean FETCH_SIZE / WRITE_SIZE (KB) per launch of the char-conv GEMM (gate epilogue, big tiles) from the
 two rocprofv3 --pmc CSVs -> profiles/<name>_traffic.json.
-    python scripts/pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv out.json"""
+    python scripts/pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv out.json [CfgI8]
+(the optional 4th argument names the tile configuration of the kernel: CfgBig = bf16x3 tiles, the
+default; CfgI8 = the int8x2 tile)"""
 import csv
 import json
 import sys
+
+
+TAG = sys.argv[4] if len(sys.argv) > 4 else "CfgBig"
 
 
 def mean_kb(path, counter):
@@ -11,7 +16,7 @@ def mean_kb(path, counter):
     with open(path) as f:
         for r in csv.DictReader(f):
             n = r["Kernel_Name"]
-            if "gemm_kernel<4" in n and "CfgBig" in n and r["Counter_Name"] == counter:
+            if "gemm_kernel<4" in n and TAG in n and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return sum(vals) / max(len(vals), 1), len(vals)
 
@@ -19,7 +24,8 @@ def mean_kb(path, counter):
 fetch, nf = mean_kb(sys.argv[1], "FETCH_SIZE")
 write, nw = mean_kb(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel": "gemm_kernel<GATE, bf16x3, big tiles> (char conv, layers>=1)", "config": 1,
+    "kernel": "gemm_kernel<GATE, %s> (char conv, layers>=1)" % ("int8x2, CfgI8" if TAG == "CfgI8" else "bf16x3, big tiles"),
+    "config": 1,
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches": [nf, nw],
     "correction": "gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads (LDS-DMA) at 64 bytes: "
                   "doubled; WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",

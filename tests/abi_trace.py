@@ -72,7 +72,7 @@ class TraceLib:
         return b""
 
     def cube_abi_version(self):
-        return 7
+        return hip.ABI_VERSION
 
     def cube_gemm_bf16(self, ref, stream):
         a = ref._obj
@@ -118,6 +118,44 @@ class TraceLib:
                 self._need("gemm " + nm, p, 2 * ((M - 1) * ld + c + nv), 2)
         return 0
 
+    def cube_gemm_i8x2(self, ref, w_scale, stream):
+        """int8x2 planes: 1 byte per element, 64-channel chunks, gate epilogue into int8 planes."""
+        a = ref._obj
+        self.calls.append(("gemm_i8x2", a.epilogue, a.M, a.N, a.Kc, a.taps))
+        M, N, Kc, taps = a.M, a.N, a.Kc, a.taps
+        assert a.epilogue == hip.EPI_GATE and a.A_lo and a.W_lo and a.out0 and a.out0_lo
+        assert not a.res and not a.rowmap and not a.out1 and not a.out2
+        assert Kc % 64 == 0 and N % 128 == 0 and a.lda >= Kc and a.lda % 16 == 0
+        nv = a.n_valid if a.n_valid > 0 else N // 2
+        assert nv % 16 == 0 and a.ldo0 % 16 == 0 and a.col0 % 16 == 0 and a.ldo0 >= a.col0 + nv
+        for nm, p in (("A", a.A), ("A_lo", a.A_lo)):
+            self._need("gemm_i8x2 " + nm, p, (M - 1) * a.lda + Kc, 16)
+        for nm, p in (("W", a.W), ("W_lo", a.W_lo)):
+            self._need("gemm_i8x2 " + nm, p, N * taps * Kc, 16)
+        self._need("gemm_i8x2 w_scale", w_scale, 4 * N, 4)
+        self._need("gemm_i8x2 bias", a.bias, 4 * N, 4)
+        out_rows, n_words = M, M
+        if a.groups:
+            cg = a.groups.contents
+            assert 1 <= cg.n <= 32
+            out_rows = n_words = 0
+            for g in range(cg.n):
+                assert cg.seq_in[g] > 0 and cg.n_rows[g] % cg.seq_in[g] == 0 and 0 < cg.seq_out[g] <= cg.seq_in[g]
+                assert cg.row0_in[g] >= 0 and cg.row0_in[g] + cg.n_rows[g] <= M
+                nw = cg.n_rows[g] // cg.seq_in[g]
+                out_rows = max(out_rows, cg.row0_out[g] + nw * cg.seq_out[g])
+                n_words = max(n_words, cg.word0[g] + nw)
+        else:
+            assert taps == 1 or (a.seq_len > 0 and M % a.seq_len == 0)
+        if a.bias_tab:
+            assert a.row_group and taps <= 5 and a.n_groups > 0
+            grp = self._ints("gemm_i8x2 row_group", a.row_group, n_words)
+            assert grp.min() >= 0 and grp.max() < a.n_groups
+            self._need("gemm_i8x2 bias_tab", a.bias_tab, 4 * a.n_groups * 32 * N, 4)
+        for nm, p in (("out0", a.out0), ("out0_lo", a.out0_lo)):
+            self._need("gemm_i8x2 " + nm, p, (out_rows - 1) * a.ldo0 + a.col0 + nv, 16)
+        return 0
+
     def cube_gather_rows(self, dst, dst_lo, ld_dst, col0, width, table, table_lo, ld_table, idx, dst_rows, n, stream):
         self.calls.append(("gather", n, width))
         if n <= 0 or width <= 0:
@@ -136,22 +174,34 @@ class TraceLib:
             self._need("gather dst" + nm, d, 2 * (dmax * ld_dst + col0 + width), 2)
         return 0
 
+    def cube_masked_mean_i8(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
+                            stream):
+        assert x_lo is not None and C % 16 == 0 and ld_x % 16 == 0
+        return self.cube_masked_mean(x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
+                                     stream, esz=1)
+
     def cube_masked_mean(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
-                         stream):
+                         stream, esz=2):
         self.calls.append(("masked_mean", n_layers, N, W, C))
         assert 0 < n_layers <= 8 and C <= ld_x and C <= ld_out
         lens = np.clip(self._ints("masked_mean len", length, N), 0, W)
         wr = self._ints("masked_mean word_rows", word_rows, n_layers * N).reshape(n_layers, N) if word_rows else None
         for k in range(n_layers):
             last = int((wr[k] + np.maximum(lens, 1) - 1).max()) if wr is not None else N * W - 1
-            self._need("masked_mean x_hi[%d]" % k, x_hi[k], 2 * (last * ld_x + C), 2)
+            self._need("masked_mean x_hi[%d]" % k, x_hi[k], esz * (last * ld_x + C), 16 if esz == 1 else 2)
             if x_lo is not None:
-                self._need("masked_mean x_lo[%d]" % k, x_lo[k], 2 * (last * ld_x + C), 2)
+                self._need("masked_mean x_lo[%d]" % k, x_lo[k], esz * (last * ld_x + C), 16 if esz == 1 else 2)
         for nm, p in (("out", out), ("out_lo", out_lo)):
             self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
         return 0
 
-    def cube_char_conv0_lookup(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream):
+    def cube_char_conv0_lookup_i8(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream):
+        assert out_lo is not None
+        return self.cube_char_conv0_lookup(T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream,
+                                           esz=1)
+
+    def cube_char_conv0_lookup(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream,
+                               esz=2):
         cg = groups.contents
         self.calls.append(("conv0_lookup", cg.n, half))
         assert taps in (1, 3, 5) and half % 4 == 0 and ld_out >= half and 1 <= cg.n <= 32
@@ -168,7 +218,7 @@ class TraceLib:
         self._need("conv0 T", T, 4 * taps * n_combo * 2 * half, 16)
         self._need("conv0 btab", btab, 4 * (int(lw.max()) + 1) * 32 * 2 * half, 16)
         for nm, p in (("out", out), ("out_lo", out_lo)):
-            self._need("conv0 " + nm, p, 2 * ((total - 1) * ld_out + half), 8)
+            self._need("conv0 " + nm, p, esz * ((total - 1) * ld_out + half), 8)
         return 0
 
     def cube_ext_finish(self, acc, ld_acc, B, L, root, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):

@@ -115,15 +115,17 @@ _CASES = [(cases.FULL, "full_8x32", "g3_forward_full.npz"), (cases.FULL, "full_2
           (cases.FULL, "ragged", "g3_forward_full.npz")]
 
 
+@pytest.mark.parametrize("i8", [True, False])
 @pytest.mark.parametrize("case,doc_key,fixture", _CASES)
-def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixture):
-    """`Parser.char_int8` against the reference's own outputs, to the bar of the default mode."""
+def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixture, i8):
+    """`Parser.char_int8` on (the default) and off (bf16x3 in the character CNN too) against the
+    reference's own outputs, to the same bar."""
     from cube_amd.networks.parser import Parser
     from cube_amd.networks.utils import MorphoCollate
     from tests.test_gpu_parity import REL_TOL, _margin_ok, _rel
     cfg, enc, sd = cases.parser_model(case)
     p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
-    p.char_int8 = True
+    p.char_int8 = i8
     p.load_state_dict(sd)
     p.to(dev)
     doc = cases.document(case, enc, doc_key)
@@ -131,7 +133,7 @@ def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixt
     X.pop("y_upos")
     r = p.decode_batch(X)
     torch.cuda.synchronize()
-    assert "xc_q1" in p._buf._b, "the int8x2 path did not run"
+    assert ("xc_q1" in p._buf._b) == i8 and ("xc_g1" in p._buf._b) == (not i8), "wrong character-CNN path ran"
     g = np.load(os.path.join(golden_dir, fixture))
     sl = r["bt"]["lens"].cpu().numpy()
     arc, ref_arc = r["arc_logits"].cpu().numpy(), g["%s/arc_logits" % doc_key]
@@ -151,5 +153,5 @@ def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixt
     nbad, agree = _margin_ok(ref_lab[same], r["labels"].cpu().numpy()[same], np.argmax(ref_lab, -1)[same],
                              REL_TOL * np.abs(ref_lab).max())
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
-    print("int8x2 %s: arc %.2e upos %.2e label %.2e" % (doc_key, _rel(arc, ref_arc),
+    print("char_int8=%s %s: arc %.2e upos %.2e label %.2e" % (i8, doc_key, _rel(arc, ref_arc),
           _rel(r["upos_logits"].cpu().numpy(), g["%s/upos" % doc_key]), _rel(lab[same], ref_lab[same])))
