@@ -16,8 +16,6 @@
 //
 // Epilogues are fused: bias, tanh / relu, the tanh*sigmoid gate with residual accumulation,
 // row scatter (unpack), hi/lo splitting of bf16 outputs.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -57,8 +55,9 @@ struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR
 // int8x2 operands (cube_gemm_i8x2): two int32 accumulator sets per output (the slice products differ
 // by 2^7), so a wave keeps 64x64; 256x128 / 8 waves (4x2).  Tall and narrow: the activation slab is
 // staged once per 5 taps, the weight tile once per tap, so rows are the cheaper side to extend.
+// Measured: three weight stages 134.4k sentences/s, two 132.9k; a 128x128 tile on 4 waves at two blocks
+// per CU 128.2k (dropped).
 struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 3; };
-struct CfgI8s { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, SR = 176, NB = 2; };  // 4 waves, 2 blocks per CU
 
 constexpr int MAX_TAPS = 5;
 template <class C> constexpr int slab_rows() { return C::SR; }
@@ -717,9 +716,7 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       if (i8) {
         if (half % 16 || a->ldo0 % 16 || a->col0 % 16 || !aligned16(a->out0) || !aligned16(a->out0_lo))
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: out0 planes need 16-byte aligned rows (half, ldo0, col0 multiples of 16)");
-        static const int i8cfg = getenv("CUBE_I8_CFG") ? atoi(getenv("CUBE_I8_CFG")) : 0;
-        rc = i8cfg == 1 ? launch_cfg<CUBE_EPI_GATE, true, CfgI8s, true>(p, cg, st)
-                        : launch_cfg<CUBE_EPI_GATE, true, CfgI8, true>(p, cg, st);
+        rc = launch_cfg<CUBE_EPI_GATE, true, CfgI8, true>(p, cg, st);
         break;
       }
       rc = launch<CUBE_EPI_GATE>(p, cg, st);
