@@ -56,7 +56,7 @@ struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR
 // by 2^7), so a wave keeps 64x64; 256x128 / 8 waves (4x2).  Tall and narrow: the activation slab is
 // staged once per 5 taps, the weight tile once per tap, so rows are the cheaper side to extend.
 // Measured: three weight stages 134.4k sentences/s, two 132.9k; a 128x128 tile on 4 waves at two blocks
-// per CU 128.2k (dropped).
+// per CU 128.2k, 128x64 per wave on 4 waves (accumulators in AGPRs, one wave per SIMD) 121.1k (both dropped).
 struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 3; };
 
 constexpr int MAX_TAPS = 5;
