@@ -57,7 +57,14 @@ struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR
 // staged once per 5 taps, the weight tile once per tap, so rows are the cheaper side to extend.
 // Measured: three weight stages 134.4k sentences/s, two 132.9k; a 128x128 tile on 4 waves at two blocks
 // per CU 128.2k, 128x64 per wave on 4 waves (accumulators in AGPRs, one wave per SIMD) 121.1k (both dropped).
-struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 3; };
+// NB = 4: k-steps run in PAIRS between barriers (a k-step of this tile is only 24 MFMAs per wave, so
+// the per-step barrier, first fragment reads and DMA drain weigh twice what they do in the bf16 tile).
+// Step s reads weight stage s % 4; its DMAs for step s + 2 go to stage (s + 2) % 4, last read at step
+// s - 2, i.e. before the previous pair's barrier; the full-drain barrier follows every odd step, so
+// everything issued in a pair has landed before the next pair.  The activation slab of chunk kc + 1
+// goes out on taps 1..3 of chunk kc only: tap 0 may share its pair with the last tap of chunk kc - 1
+// (still reading that buffer), tap 4 with the first tap of chunk kc + 1 (already reading the new one).
+struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 4; };
 
 constexpr int MAX_TAPS = 5;
 template <class C> constexpr int slab_rows() { return C::SR; }
@@ -142,13 +149,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   constexpr int A_PLANE = SR * ROWB, B_PLANE = BN * ROWB;
   constexpr int A_BUF = NP * A_PLANE, B_BUF = NP * B_PLANE;
   constexpr int B_BASE = 2 * A_BUF;
-  constexpr int NB = C::NB, PD = NB - 1;                     // weight-tile stages, prefetch distance (k-steps)
+  constexpr int NB = C::NB, PD = NB == 4 ? 2 : NB - 1;       // weight-tile stages, prefetch distance (k-steps)
+  constexpr bool PAIRS = NB == 4;                            // two k-steps per barrier (see CfgI8)
   constexpr int ZERO_OFF = 2 * A_BUF + NB * B_BUF;
   constexpr int A_PIECES = SR / 16, B_PIECES = BN / 16;      // 1-KiB DMA pieces per plane
   constexpr int PA = (A_PIECES + NW - 1) / NW, PB = (B_PIECES + NW - 1) / NW;
   constexpr bool B_EVEN = B_PIECES % NW == 0;                // every wave issues PB weight pieces per tile
   static_assert(TN == 2, "the gate epilogue pairs the two 32-column tiles of a wave");
-  static_assert(NB == 2 || NB == 3, "two or three weight stages");
+  static_assert(NB == 2 || NB == 3 || NB == 4, "two or three weight stages, or four with paired k-steps");
   static_assert(B_EVEN || B_PIECES % NW > 0, "");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 
   ISSUE_A(0, 0)
   ISSUE_B(0, 0)
-  if constexpr (NB == 3) {
+  if constexpr (NB >= 3) {
     if (nk > 1) ISSUE_B(1, 1)
   }
   __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables
@@ -351,12 +359,12 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
       // of step s+1) has landed.
 #pragma unroll
       for (int q = u * PPU; q < (u + 1) * PPU && q < PA + PB; ++q) {
-        const int qb = NB == 2 ? q : q - PA, qa = NB == 2 ? q - PB : q;
+        const int qb = NB != 3 ? q : q - PA, qa = NB != 3 ? q - PB : q;
         if (qb >= 0 && qb < PB) {
           if (pre) ISSUE_B_PIECE(s + PD, stg_pre, qb)
         } else if (qa >= 0 && qa < PA) {
-          if (kc + 1 < nkc) {
-            const int a = qa * taps + tap;  // wave-uniform
+          if (kc + 1 < nkc && (!PAIRS || (tap >= 1 && tap <= taps - 2))) {
+            const int a = PAIRS ? qa * (taps - 2) + tap - 1 : qa * taps + tap;  // wave-uniform
 #pragma unroll
             for (int ai = 0; ai < PA; ++ai)
               if (a == ai) ISSUE_A_PIECE(kc + 1, (kc + 1) & 1, ai)
@@ -366,6 +374,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     }
     if constexpr (NB == 2) {
       __syncthreads();  // also drains this step's LDS-DMA (vmcnt(0))
+    } else if constexpr (PAIRS) {
+      if ((s & 1) || s == nk - 1) __syncthreads();
     } else {
       // every wave waits for its own older DMAs, then the barrier: after it all pieces of step s+1
       // (from all waves) are in LDS, and all reads of stage `stg` (restaged next step) are done
@@ -641,6 +651,7 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   if ((a->A_lo == nullptr) != (a->W_lo == nullptr))
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: A_lo and W_lo must be given together (bf16x3) or not at all (bf16)");
   if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: taps=%d", a->taps);
+  if (i8 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: taps=%d (the int8x2 tile is built for Conv1d(k=5))", a->taps);
   if (a->Kc <= 0 || a->Kc % BKC) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BKC);
   if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of 128", a->N);
   if (a->lda < a->Kc || a->lda % (i8 ? 16 : 8)) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
