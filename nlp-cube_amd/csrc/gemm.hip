@@ -311,43 +311,57 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
       aoff[i] = ok ? (kc & 1) * A_BUF + lds_off(row, lh) : ZERO_OFF;
       alo[i] = ok ? A_PLANE : 0;
     }
+    // AD = how many units the activation fragments run ahead.  The int8x2 tile's units are short (6 MFMAs)
+    // and two waves' reads queue in front of each other: two units ahead, and the second k-substep's
+    // weight fragments right behind the first's.
+    constexpr int AD = I8 ? 2 : 1, AR = AD + 1;
     frag_t fb[2][NP][TN];
-    frag_t fa[2][NP];
+    frag_t fa[AR][NP];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[0][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][0]);
-    fa[0][0] = *reinterpret_cast<const frag_t*>(smem + aoff[0]);
-    if constexpr (SPLIT) fa[0][1] = *reinterpret_cast<const frag_t*>(smem + aoff[0] + alo[0]);
+#pragma unroll
+    for (int u0 = 0; u0 < AD && u0 < 2 * TM; ++u0) {
+      const int o = aoff[u0 % TM] ^ (u0 / TM ? 32 : 0);
+      fa[u0][0] = *reinterpret_cast<const frag_t*>(smem + o);
+      if constexpr (SPLIT) fa[u0][1] = *reinterpret_cast<const frag_t*>(smem + o + alo[u0 % TM]);
+    }
+    if constexpr (AD > 1) {
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[1][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][1]);
+    }
 #pragma unroll
     for (int u = 0; u < 2 * TM; ++u) {
       const int ks = u / TM, i = u % TM;
-      if (u + 1 < 2 * TM) {  // prefetch the next unit's A fragments (and, once, the second k-substep's B)
-        const int ks2 = (u + 1) / TM, i2 = (u + 1) % TM;
+      if (u + AD < 2 * TM) {  // prefetch a later unit's A fragments
+        const int ks2 = (u + AD) / TM, i2 = (u + AD) % TM;
         // chunk = (2*ks + lh) ^ swz: the k-substep toggles bit 1 of the chunk index = offset ^ 32
         const int o = aoff[i2] ^ (ks2 ? 32 : 0);
-        fa[(u + 1) & 1][0] = *reinterpret_cast<const frag_t*>(smem + o);
-        if constexpr (SPLIT) fa[(u + 1) & 1][1] = *reinterpret_cast<const frag_t*>(smem + o + alo[i2]);
-        if (u + 1 == TM) {
+        fa[(u + AD) % AR][0] = *reinterpret_cast<const frag_t*>(smem + o);
+        if constexpr (SPLIT) fa[(u + AD) % AR][1] = *reinterpret_cast<const frag_t*>(smem + o + alo[i2]);
+      }
+      if (AD == 1 && u + 1 == TM) {  // once, the second k-substep's B
 #pragma unroll
-          for (int pl = 0; pl < NP; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              fb[1][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][1]);
-        }
+          for (int j = 0; j < TN; ++j)
+            fb[1][pl][j] = *reinterpret_cast<const frag_t*>(bbase + pl * B_PLANE + b_rd[j][1]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (I8) {
-          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][1], fb[ks][0][j], acc2[i][j], 0, 0, 0);
-          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][0], fb[ks][1][j], acc2[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][1], fb[ks][0][j], acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][1][j], acc2[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
         } else {
           if constexpr (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u % AR][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u % AR][0], fb[ks][1][j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u % AR][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
         }
       }
       // DMA slots q of this unit: the weight pieces of step s+PD and the activation pieces of the
