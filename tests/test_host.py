@@ -259,3 +259,30 @@ def test_host_helper_matches_numpy_collate(monkeypatch):
             w.emb = [e.tolist() for e in w.emb]
     c = col.collate_fn(doc.sentences)
     assert all(torch.allclose(x.float(), y.float()) for x, y in zip(c["x_word_embeddings"], a["x_word_embeddings"]))
+
+
+def test_pack_gated_conv_int8_planes():
+    """int8x2 weight planes of cube_gemm_i8x2 (include/cube_hip.h): slice ranges, 64-channel chunk layout and
+    the per-column scale reproduce the BN-folded fp32 weights to 15 bits; layers whose input width is not a
+    multiple of 64 channels get no int8 planes (the host then stays in bf16x3)."""
+    g = torch.Generator().manual_seed(5)
+    half, cin, lang = 64, 128, 16
+    sd = {"c.0.conv.weight": torch.randn((2 * half, cin + lang, 5), generator=g) * 0.05,
+          "c.0.conv.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.weight": torch.rand(2 * half, generator=g) + 0.5, "c.1.bias": torch.randn(2 * half, generator=g) * 0.1,
+          "c.1.running_mean": torch.randn(2 * half, generator=g) * 0.1, "c.1.running_var": torch.rand(2 * half, generator=g) + 0.5}
+    table = torch.randn((3, lang), generator=g)
+    pk = packing.pack_gated_conv(sd, "c", np.arange(cin), double_first=half, bcast=(cin + np.arange(lang), table), int8=True)
+    hi, lo = pk["W8"].hi.to(torch.int32), pk["W8"].lo.to(torch.int32)
+    assert pk["W8"].hi.dtype == torch.int8 and hi.shape == (pk["N"], 5 * pk["Kc"])
+    assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -64 and int(lo.max()) <= 63
+    # dequantised, un-chunked (64-channel chunks, taps of a chunk adjacent) == the bf16x3 weights un-chunked (32)
+    N, Kc = pk["N"], pk["Kc"]
+    w8 = (hi * 128 + lo).double() * (pk["w_scale"].double() * hip.I8_ONE / 128.0)[:, None]
+    w8 = w8.view(N, Kc // 64, 5, 64).permute(0, 2, 1, 3).reshape(N, 5, Kc)
+    wf = pk["W"].float().double().view(N, Kc // 32, 5, 32).permute(0, 2, 1, 3).reshape(N, 5, Kc)
+    rowmax = wf.abs().amax(dim=(1, 2)).clamp(min=1e-30)
+    assert float(((w8 - wf).abs().amax(dim=(1, 2)) / rowmax).max()) < 2.0 ** -14
+    # the whole-tensor scale: one unit of (128*HH + X) with activations in units of 1/I8_ONE
+    np.testing.assert_allclose(pk["w_scale"].numpy(), (rowmax * 128.0 / hip.I8_ONE ** 2).float().numpy(), rtol=1e-3)
+    assert "W8" not in packing.pack_gated_conv(sd, "c", np.arange(32), int8=True)  # Kc = 32
