@@ -660,43 +660,44 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   const bool i8 = w_scale != nullptr;
   const int BKC = i8 ? 2 * BK : BK;  // channels per 64-byte LDS row
-  if (!a) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null args");
+  const char* fn = i8 ? "cube_gemm_i8x2" : "cube_gemm_bf16";
+  if (!a) CUBE_FAIL(CUBE_ERR_ARG, "%s: null args", fn);
   if (a->M <= 0) return CUBE_OK;
-  if (!a->A || !a->W) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: null operand");
+  if (!a->A || !a->W) CUBE_FAIL(CUBE_ERR_ARG, "%s: null operand", fn);
   if ((a->A_lo == nullptr) != (a->W_lo == nullptr))
-    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: A_lo and W_lo must be given together (bf16x3) or not at all (bf16)");
-  if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: taps=%d", a->taps);
+    CUBE_FAIL(CUBE_ERR_ARG, "%s: A_lo and W_lo must be given together (bf16x3) or not at all (bf16)", fn);
+  if (a->taps != 1 && a->taps != 3 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "%s: taps=%d", fn, a->taps);
   if (i8 && a->taps != 5) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: taps=%d (the int8x2 tile is built for Conv1d(k=5))", a->taps);
-  if (a->Kc <= 0 || a->Kc % BKC) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: Kc=%d not a multiple of %d", a->Kc, BKC);
-  if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: N=%d not a multiple of 128", a->N);
-  if (a->lda < a->Kc || a->lda % (i8 ? 16 : 8)) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: lda=%d (Kc=%d)", a->lda, a->Kc);
+  if (a->Kc <= 0 || a->Kc % BKC) CUBE_FAIL(CUBE_ERR_ARG, "%s: Kc=%d not a multiple of %d", fn, a->Kc, BKC);
+  if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "%s: N=%d not a multiple of 128", fn, a->N);
+  if (a->lda < a->Kc || a->lda % (i8 ? 16 : 8)) CUBE_FAIL(CUBE_ERR_ALIGN, "%s: lda=%d (Kc=%d)", fn, a->lda, a->Kc);
   if (i8 && (a->epilogue != CUBE_EPI_GATE || !a->A_lo || !a->W_lo || a->res || a->out1 || a->out2 || !a->out0 || !a->out0_lo))
     CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: int8x2 needs both planes of A, W and out0, the gate epilogue and no residual stream");
   if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->A_lo) || !aligned16(a->W_lo))
-    CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_bf16: operands must be 16-byte aligned");
+    CUBE_FAIL(CUBE_ERR_ALIGN, "%s: operands must be 16-byte aligned", fn);
   ConvGroups cg;
   cg.n = 0;
   if (a->groups) {
     cg = *a->groups;
-    if (cg.n <= 0 || cg.n > CUBE_MAX_CONV_GROUPS) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: %d sequence groups (1..%d)", cg.n, CUBE_MAX_CONV_GROUPS);
+    if (cg.n <= 0 || cg.n > CUBE_MAX_CONV_GROUPS) CUBE_FAIL(CUBE_ERR_ARG, "%s: %d sequence groups (1..%d)", fn, cg.n, CUBE_MAX_CONV_GROUPS);
     if (a->epilogue != CUBE_EPI_GATE || a->res || a->rowmap)
-      CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: sequence groups need the gate epilogue without residual stream / rowmap");
+      CUBE_FAIL(CUBE_ERR_ARG, "%s: sequence groups need the gate epilogue without residual stream / rowmap", fn);
     for (int g = 0; g < cg.n; ++g) {
       if (cg.seq_in[g] <= 0 || cg.n_rows[g] <= 0 || cg.n_rows[g] % cg.seq_in[g] || cg.seq_out[g] <= 0 ||
           cg.seq_out[g] > cg.seq_in[g] || cg.row0_in[g] < 0 || cg.row0_in[g] + cg.n_rows[g] > a->M || cg.row0_out[g] < 0 ||
           cg.word0[g] < 0)
-        CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad sequence group %d", g);
+        CUBE_FAIL(CUBE_ERR_ARG, "%s: bad sequence group %d", fn, g);
     }
   }
   const int seq = (a->taps == 1 || a->groups) ? a->M : a->seq_len;
-  if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: M=%d not a multiple of seq_len=%d", a->M, seq);
+  if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "%s: M=%d not a multiple of seq_len=%d", fn, a->M, seq);
   GemmParams p;
   p.vec_out = 0; p.m_tiles = p.n_tiles = 0;
   p.bias_tab = a->bias_tab; p.row_group = a->row_group;
   if ((a->bias_tab == nullptr) != (a->row_group == nullptr))
-    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab and row_group go together");
+    CUBE_FAIL(CUBE_ERR_ARG, "%s: bias_tab and row_group go together", fn);
   if (a->bias_tab && (a->epilogue != CUBE_EPI_GATE || a->taps > 5 || a->n_groups <= 0))
-    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bias_tab needs the gate epilogue, taps <= 5 and n_groups > 0");
+    CUBE_FAIL(CUBE_ERR_ARG, "%s: bias_tab needs the gate epilogue, taps <= 5 and n_groups > 0", fn);
   p.w_scale = w_scale;
   // int8 planes: the kernel counts in 2-byte units (its addressing is then the bf16 one, byte for byte)
   p.A = (const uint16_t*)a->A; p.A_lo = (const uint16_t*)a->A_lo; p.lda = i8 ? a->lda / 2 : a->lda; p.M = a->M; p.seq_len = seq;
@@ -708,35 +709,35 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   p.res = a->res; p.ld_res = a->ld_res; p.res_mode = a->res_mode;
   p.out1 = (uint16_t*)a->out1; p.out1_lo = (uint16_t*)a->out1_lo; p.ldo1 = a->ldo1; p.col1 = a->col1;
   p.out2 = (uint16_t*)a->out2; p.out2_lo = (uint16_t*)a->out2_lo; p.ldo2 = a->ldo2; p.col2 = a->col2;
-  if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: n_valid=%d > N=%d", p.n_valid, a->N);
+  if (p.n_valid > a->N) CUBE_FAIL(CUBE_ERR_ARG, "%s: n_valid=%d > N=%d", fn, p.n_valid, a->N);
   hipStream_t st = (hipStream_t)stream;
   int rc = CUBE_OK;
   switch (a->epilogue) {
     case CUBE_EPI_F32:
-      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
+      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out0/ldo0", fn);
       rc = launch<CUBE_EPI_F32>(p, cg, st);
       break;
     case CUBE_EPI_BF16:
     case CUBE_EPI_BF16_TANH:
     case CUBE_EPI_BF16_RELU:
-      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
+      if (!a->out0 || a->ldo0 < a->col0 + p.n_valid) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out0/ldo0", fn);
       if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, cg, st);
       else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, cg, st);
       else rc = launch<CUBE_EPI_BF16_RELU>(p, cg, st);
       break;
     case CUBE_EPI_GATE: {
       const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile
-      if (half > a->N / 2) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate n_valid=%d > N/2", half);
-      if (a->res && a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs res[M, >=%d]", half);
-      if (!a->res && (a->out1 || a->out2)) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: out1/out2 (x + res) need res");
-      if (!a->res && !a->out0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue without any output");
+      if (half > a->N / 2) CUBE_FAIL(CUBE_ERR_ARG, "%s: gate n_valid=%d > N/2", fn, half);
+      if (a->res && a->ld_res < half) CUBE_FAIL(CUBE_ERR_ARG, "%s: gate epilogue needs res[M, >=%d]", fn, half);
+      if (!a->res && (a->out1 || a->out2)) CUBE_FAIL(CUBE_ERR_ARG, "%s: out1/out2 (x + res) need res", fn);
+      if (!a->res && !a->out0) CUBE_FAIL(CUBE_ERR_ARG, "%s: gate epilogue without any output", fn);
       if (a->res_mode < 0 || a->res_mode > 3 || (a->res_mode == 3 && !a->res))
-        CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: res_mode=%d", a->res_mode);
-      if (a->rowmap) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: rowmap is not supported by the gate epilogue");
-      if (a->out0 && a->ldo0 < a->col0 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out0/ldo0");
-      if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out1/ldo1");
-      if (a->out2 && a->ldo2 < a->col2 + half) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: bad out2/ldo2");
-      if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: gate epilogue needs a bias");
+        CUBE_FAIL(CUBE_ERR_ARG, "%s: res_mode=%d", fn, a->res_mode);
+      if (a->rowmap) CUBE_FAIL(CUBE_ERR_ARG, "%s: rowmap is not supported by the gate epilogue", fn);
+      if (a->out0 && a->ldo0 < a->col0 + half) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out0/ldo0", fn);
+      if (a->out1 && a->ldo1 < a->col1 + half) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out1/ldo1", fn);
+      if (a->out2 && a->ldo2 < a->col2 + half) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out2/ldo2", fn);
+      if (!a->bias) CUBE_FAIL(CUBE_ERR_ARG, "%s: gate epilogue needs a bias", fn);
       p.vec_out = !a->res && a->out0 && half % 8 == 0 && a->ldo0 % 8 == 0 && a->col0 % 8 == 0 && aligned16(a->out0) &&
                   aligned16(a->out0_lo);
       if (i8) {
@@ -749,10 +750,10 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       break;
     }
     default:
-      CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: unknown epilogue %d", a->epilogue);
+      CUBE_FAIL(CUBE_ERR_ARG, "%s: unknown epilogue %d", fn, a->epilogue);
   }
   if (rc != CUBE_OK) return rc;
-  CUBE_CHECK_LAUNCH("cube_gemm_bf16");
+  CUBE_CHECK_LAUNCH(fn);
   return CUBE_OK;
 }
 

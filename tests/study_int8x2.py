@@ -1,4 +1,4 @@
-"""Design study for the next round (not a test; run by hand: python tests/study_int8x2.py).
+"""Design study that preceded cube_gemm_i8x2 (not a test; run by hand: python tests/study_int8x2.py).
 
 Would a two-slice int8 fixed-point split of the gated-convolution GEMMs (int8 MFMA runs at twice the
 bf16 rate and moves half the bytes; three slice products instead of three bf16 passes) stay inside the
