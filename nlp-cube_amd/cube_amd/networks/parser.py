@@ -10,6 +10,9 @@ hi/lo pair of bf16 planes and forms each product as hi*hi + hi*lo + lo*hi on the
 with fp32 accumulation — fp32-grade results, checked directly against the reference's own
 outputs (tests/golden) to the north-star tolerance; "bf16" is the single-pass mode (one
 plane, 3x fewer MFMAs) whose arithmetic contract is oracle/parser_oracle.py quant="bf16".
+In bf16x3 mode the character-CNN layers >= 1 (inputs = gate outputs, |x| < 1) run in two-slice
+int8 fixed point (`char_int8`, default on; cube_gemm_i8x2 in include/cube_hip.h): exact int32
+accumulation of the slice products, 2.6e-5 on the reference's arc scores.
 
 Per batch: 1 upload of int32 indices + bf16 external embeddings, ~45 asynchronous kernel
 launches on the current HIP stream, 1 download of five int32 arrays — the reference's three
