@@ -197,6 +197,7 @@ size_t cube_mst_workspace_bytes(int B, int L);
 int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L,
                     int32_t* heads, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+
 /* Label scores for the decoded heads.  hl bf16 [B*T, ld_hl]: x1 = cols [0, D), x2 = cols
  * [col_x2, col_x2+D) (each with its constant-1 column inside D), D % 32 == 0.
  * wl bf16 [n_labels][D][D] ([o][q][p] = W[o,p,q]); bias f32 [n_labels];

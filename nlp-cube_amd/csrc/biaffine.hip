@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void biaffine_arc_kernel(const uint16_t* __rest
 extern "C" int cube_biaffine_arc(const void* u, const void* u_lo, int ld_u, const void* h2, const void* h2_lo,
                                  int ld_h2, int col_h2, int D, int B, int T, float* logits, float* probs,
                                  void* stream) {
+  CUBE_ENTRY();
   if (B <= 0 || T <= 1) return CUBE_OK;
   if (!u || !h2 || !logits || !probs) CUBE_FAIL(CUBE_ERR_ARG, "cube_biaffine_arc: null pointer");
   if (D <= 0 || D % 16 || D > ld_u || col_h2 < 0 || col_h2 + D > ld_h2) CUBE_FAIL(CUBE_ERR_ARG, "cube_biaffine_arc: bad D/columns");

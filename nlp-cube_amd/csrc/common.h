@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -19,6 +20,9 @@ void cube_set_error(const char* fmt, ...);
     cube_set_error(__VA_ARGS__);  \
     return (code);                \
   } while (0)
+// hipGetLastError() is per host thread and sticky: an error left behind by an unrelated call of the shared
+// HIP runtime (a torch op, an earlier failed launch) must not be reported by the next cube_* entry
+#define CUBE_ENTRY() ((void)hipGetLastError())
 #define CUBE_CHECK_LAUNCH(name)                                                   \
   do {                                                                            \
     hipError_t e__ = hipGetLastError();                                           \
@@ -44,18 +48,21 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember per
-// device (one process may drive several GPUs) what has been reserved for a kernel.
+// device (one process may drive several GPUs, from several host threads) what has been reserved for
+// a kernel.  The table is atomic: two threads that race on the first launch both set the attribute
+// (idempotent) and both record it; nothing else in the library is mutable process state.
 constexpr int CUBE_MAX_DEVICES = 64;
 struct CubeLdsReservation {
-  size_t bytes[CUBE_MAX_DEVICES] = {};
+  std::atomic<size_t> bytes[CUBE_MAX_DEVICES] = {};
   // true if `lds` bytes are (now) reserved for `fn` on the current device
   bool ensure(const void* fn, size_t lds) {
     if (lds <= 65536) return true;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CUBE_MAX_DEVICES) return false;
-    if (bytes[dev] >= lds) return true;
+    if (bytes[dev].load(std::memory_order_acquire) >= lds) return true;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-    bytes[dev] = lds;
+    size_t seen = bytes[dev].load(std::memory_order_relaxed);
+    while (seen < lds && !bytes[dev].compare_exchange_weak(seen, lds, std::memory_order_release)) {}
     return true;
   }
 };

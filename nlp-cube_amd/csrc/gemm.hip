@@ -762,6 +762,8 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
 extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) { return gemm_entry(a, nullptr, stream); }
 
 extern "C" int cube_gemm_i8x2(const cube_gemm_args* a, const float* w_scale, void* stream) {
+  CUBE_ENTRY();
+  CUBE_ENTRY();
   if (!w_scale) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: null w_scale");
   return gemm_entry(a, w_scale, stream);
 }

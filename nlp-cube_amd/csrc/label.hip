@@ -165,6 +165,7 @@ int launch_label(bool split, dim3 grid, hipStream_t st, const uint16_t* hl, cons
 extern "C" int cube_label_score(const void* hl, const void* hl_lo, int ld_hl, int col_x2, int D, const void* wl,
                                 const void* wl_lo, const float* bias, int n_labels, const int32_t* heads,
                                 const int32_t* lens, int B, int L, float* logits, int32_t* labels, void* stream) {
+  CUBE_ENTRY();
   if (B <= 0 || L <= 0 || n_labels <= 0) return CUBE_OK;
   if (!hl || !wl || !bias || !heads || !lens || !logits) CUBE_FAIL(CUBE_ERR_ARG, "cube_label_score: null pointer");
   if ((hl_lo == nullptr) != (wl_lo == nullptr)) CUBE_FAIL(CUBE_ERR_ARG, "cube_label_score: hl_lo and wl_lo go together");

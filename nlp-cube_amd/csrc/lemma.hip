@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int cube_lemma_attend(const cube_lemma_attend_args* a, void* stream) {
+  CUBE_ENTRY();
   if (!a) CUBE_FAIL(CUBE_ERR_ARG, "cube_lemma_attend: null args");
   if (a->B <= 0) return CUBE_OK;
   if (!a->q || !a->x || a->ld_q <= 0 || a->ld_x <= 0 || a->E < 0 || a->col_emb < 0 || a->col_emb + a->E > a->ld_x)
@@ -224,6 +225,7 @@ extern "C" int cube_lemma_attend(const cube_lemma_attend_args* a, void* stream) 
 
 extern "C" int cube_lstm_cell(const float* gates, int ld_g, int H, float* c, int B, void* h, void* h_lo, int ld_h, int col_h,
                               void* c16, void* c16_lo, int col_c, void* stream) {
+  CUBE_ENTRY();
   if (B <= 0) return CUBE_OK;
   if (!gates || !c || !h || H <= 0 || ld_g < 4 * H || col_h < 0 || col_h + H > ld_h || (c16 && (col_c < 0 || col_c + H > ld_h)))
     CUBE_FAIL(CUBE_ERR_ARG, "cube_lstm_cell: bad args (H=%d ld_g=%d ld_h=%d col_h=%d col_c=%d)", H, ld_g, ld_h, col_h, col_c);

@@ -146,6 +146,7 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const uint16_t* __re
 
 extern "C" int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, int B, int T, int H,
                                      void* out, void* out_lo, int ld_out, int col0, void* stream) {
+  CUBE_ENTRY();
   if (B <= 0 || T <= 0) return CUBE_OK;
   if (!gx || !whh || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: null pointer");
   if (H <= 0 || H > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_bilstm_recurrent: rnn_size=%d unsupported (1..256)", H);
@@ -164,8 +165,13 @@ extern "C" int cube_bilstm_recurrent(const float* gx, const void* whh, const voi
   dim3 grid((B + rows - 1) / rows, 2), block(64 * U);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_RT(KS, SP, RT)                                                                                     \
-  hipLaunchKernelGGL((bilstm_kernel<KS, SP, RT>), grid, block, lds, st, gx, (const uint16_t*)whh,                 \
-                     (const uint16_t*)whh_lo, B, T, H, (uint16_t*)out, (uint16_t*)out_lo, ld_out, col0)
+  do {                                                                                                            \
+    static CubeLdsReservation reserved; /* H > 224 with two row tiles in bf16x3 needs more than 64 KiB */         \
+    if (!reserved.ensure((const void*)bilstm_kernel<KS, SP, RT>, lds))                                            \
+      CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_bilstm_recurrent: cannot reserve %zu bytes of LDS", lds);                  \
+    hipLaunchKernelGGL((bilstm_kernel<KS, SP, RT>), grid, block, lds, st, gx, (const uint16_t*)whh,               \
+                       (const uint16_t*)whh_lo, B, T, H, (uint16_t*)out, (uint16_t*)out_lo, ld_out, col0);        \
+  } while (0)
 #define LAUNCH(KS)                                                                                                \
   case KS:                                                                                                        \
     if (split) { if (rt == 2) LAUNCH_RT(KS, true, 2); else LAUNCH_RT(KS, true, 1); }                              \

@@ -185,6 +185,11 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
     // record header + cycle
     const int need = 2 + 2 * c + 2 * nn;
     if (rec_end + need > m.rec_cap) return false;
+    // Exit condition every wave reaches: a contraction must shrink the graph.  With probabilities (>= 0,
+    // zero diagonal, node 0 first in the order) a node never selects itself, so c >= 2; scores with
+    // negative entries (not probabilities: a caller's bug, an overwritten buffer) can produce the
+    // self-loop c == 1, which would contract nothing and spin forever -- report "no tree" instead.
+    if (c < 2 || levels >= n) return false;
     uint8_t* rec = m.rec + rec_end;
     if (lane == 0) { rec[0] = (uint8_t)cur; rec[1] = (uint8_t)c; }
     for (int i = lane; i < c; i += 64) {
@@ -531,14 +536,11 @@ extern "C" size_t cube_mst_workspace_bytes(int B, int L) {
   return mst_ws_bytes(B, L);
 }
 
-extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-  if (B <= 0 || L <= 0) return CUBE_OK;
-  if (!probs || !lens || !heads || !status || !workspace) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: null pointer");
-  if (L + 1 > MST_MAX_N_GLOBAL) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
-  if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
-  if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// Launch sequence shared by cube_mst_decode and cube_mst_decode_noalloc; `workspace` holds mst_ws_bytes(B, L) bytes.
+int mst_decode_impl(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
+                    void* workspace, hipStream_t st) {
   const bool gs_first = L + 1 > MST_MAX_N, gs_root = L + 1 >= MST_ROOT_GLOBAL_N;
   const size_t lds_first = mst_lds_bytes(L + 1, gs_first), lds_root = mst_lds_bytes(L + 1, gs_root);
   static CubeLdsReservation reserved[4];
@@ -564,4 +566,17 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
   hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
   CUBE_CHECK_LAUNCH("cube_mst_decode(select)");
   return CUBE_OK;
+}
+
+}  // namespace
+
+extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  CUBE_ENTRY();
+  if (B <= 0 || L <= 0) return CUBE_OK;
+  if (!probs || !lens || !heads || !status || !workspace) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: null pointer");
+  if (L + 1 > MST_MAX_N_GLOBAL) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
+  if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
+  if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
+  return mst_decode_impl(probs, lens, B, L, heads, status, workspace, (hipStream_t)stream);
 }

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld
 extern "C" int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, const void* table,
                                 const void* table_lo, int ld_table, const int32_t* idx, const int32_t* dst_rows, int n,
                                 void* stream) {
+  CUBE_ENTRY();
   if (n <= 0 || width <= 0) return CUBE_OK;
   if (!dst || !table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: null pointer");
   if (dst_lo && !table_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows: dst_lo needs table_lo");
@@ -385,16 +386,19 @@ static int masked_mean_entry(bool i8, const void* const* x_hi, const void* const
 extern "C" int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                                 int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
                                 const int32_t* word_rows, void* stream) {
+  CUBE_ENTRY();
   return masked_mean_entry(false, x_hi, x_lo, weight, n_layers, ld_x, len, N, W, C, out, out_lo, ld_out, word_rows, stream);
 }
 extern "C" int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                                    int ld_x, const int32_t* len, int N, int W, int C, void* out, void* out_lo, int ld_out,
                                    const int32_t* word_rows, void* stream) {
+  CUBE_ENTRY();
   return masked_mean_entry(true, x_hi, x_lo, weight, n_layers, ld_x, len, N, W, C, out, out_lo, ld_out, word_rows, stream);
 }
 
 extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, void* dst_a, void* dst_a_lo,
                                int ld_a, int col_a, void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream) {
+  CUBE_ENTRY();
   if (B <= 0 || L <= 0 || P <= 0) return CUBE_OK;
   if (!acc || K <= 0 || P > ld_acc || (root != 0 && root != 1)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
   if ((dst_a && col_a + P > ld_a) || (dst_b && col_b + P > ld_b)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad columns");
@@ -440,15 +444,18 @@ static int conv0_lookup_entry(bool i8, const float* T, const float* btab, const 
 extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
                                       const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
                                       void* out_lo, int ld_out, void* stream) {
+  CUBE_ENTRY();
   return conv0_lookup_entry(false, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
 }
 extern "C" int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
                                          const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
                                          void* out_lo, int ld_out, void* stream) {
+  CUBE_ENTRY();
   return conv0_lookup_entry(true, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
 }
 
 extern "C" int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream) {
+  CUBE_ENTRY();
   if (M <= 0) return CUBE_OK;
   if (!x || !out || n <= 0 || col0 < 0 || col0 + n > ld) CUBE_FAIL(CUBE_ERR_ARG, "cube_argmax_rows: bad args");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, col0, n, M, out);

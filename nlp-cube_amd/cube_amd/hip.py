@@ -154,8 +154,27 @@ def ptr(t):
 
 
 def stream_handle():
+    """HIP stream of the CURRENT device.  Every launch path of a model runs under `on_device`, which makes
+    the model's device current first: a stream of another device with this model's pointers would fault."""
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(fn):
+    """Method decorator: run with the object's `_device` as the current HIP device (the reference lets a
+    model live on any device, `Cube.load(lang, device='cuda:1')`, api.py:207): the stream the kernels are
+    launched on, the LDS reservations of the library and torch's allocations all follow the current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = getattr(self, "_device", None)
+        if dev is None or dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        import torch
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 def _planes(x, col=0):

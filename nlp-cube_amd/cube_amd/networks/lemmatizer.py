@@ -173,6 +173,7 @@ class Lemmatizer:
                                               table.hi.data_ptr(), hip.ptr(table.lo) if lo else None, table.hi.shape[1],
                                               hip.ptr(idx), None, n, hip.stream_handle()), "cube_gather_rows")
 
+    @hip.on_device
     def _encode(self, X):
         """lemmatizer.py:89-124 + the encoder half of the attention Conv1d (modules.py:141,156).
         -> dict(B, S, enc Pair [B*S, enc_w], e_enc f32 [B*S, N])"""
@@ -210,6 +211,7 @@ class Lemmatizer:
                  n_valid=ae["N"], taps=ae["taps"], seq_len=S, stream=st)
         return dict(B=B, S=S, enc=enc, e_enc=e_enc, ld_e=ae["N"], _ints=ints)
 
+    @hip.on_device
     def _decode(self, ed, max_steps=None, keep_logits=False):
         """Greedy decoding (lemmatizer.py:126-169).  -> (out_char i32 [B, n], out_case i32 [B, n], n, logits)
         with n = the number of steps the reference would have run."""
@@ -287,6 +289,7 @@ class Lemmatizer:
                 n = int(is_eol.argmax(axis=1).max()) + 1
         return oc[:, :n], ok[:, :n], n, (None if logits is None else logits[:n])
 
+    @hip.on_device
     def forward(self, X):
         """-> (char logits [B, n, C+2], case logits [B, n, 4]) of the greedy decode, as the reference's
         inference branch returns them (lemmatizer.py:171).  Teacher forcing ('y_char' in X) is training-only
@@ -298,6 +301,7 @@ class Lemmatizer:
         logits = logits.permute(1, 0, 2)
         return logits[:, :, :self._lay.n_char], logits[:, :, self._lay.n_char:]
 
+    @hip.on_device
     def decode_batch(self, X):
         """-> (chars int32 [B, n], cases int32 [B, n]) arg-max sequences (NumPy), no logits kept."""
         self._require_gpu()
@@ -340,6 +344,7 @@ class Lemmatizer:
             out[r] = "".join(np.where(k == 2, obj[1][i], np.where(k == 3, obj[2][i], obj[0][i])).tolist())
         return out
 
+    @hip.on_device
     def process_bucketed(self, doc, collate, max_words=8192):
         """Throughput mode, no counterpart in the reference: every distinct (word, UPOS, language) is
         lemmatised ONCE, in batches of words of the SAME length (S = length + 2, so no pad positions
@@ -372,6 +377,7 @@ class Lemmatizer:
                     w.lemma = keys[(w.word, w.upos, sent.lang_id)]
         return doc
 
+    @hip.on_device
     def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_words=8192):
         """reference: lemmatizer.py:185-231.  `num_workers` is accepted and ignored.
         merge (no counterpart in the reference, results unchanged): the reference's in-order batches of

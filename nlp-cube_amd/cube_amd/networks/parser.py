@@ -143,6 +143,7 @@ class _HipNet:
     def start_kernel_timing(self, tag):
         self._timing = dict(tag=tag, pairs=[])
 
+    @hip.on_device
     def stop_kernel_timing(self):
         t, self._timing = self._timing, None
         torch.cuda.synchronize()
@@ -168,6 +169,7 @@ class _HipNet:
         return _Ctx()
 
     # ---- batch preparation -----------------------------------------------------------------
+    @hip.on_device
     def _prepare(self, X):
         """reference-format batch dict (MorphoCollate.collate_fn) -> device index arrays.
         One packed int32 upload + one (hi[, lo]) bf16 upload per LM layer."""
@@ -570,6 +572,7 @@ class Parser(_HipNet):
         return r
 
     # ---- reference API ---------------------------------------------------------------------
+    @hip.on_device
     def forward(self, X):
         """reference: parser.py:109-216.  Returns (arc logits [B,L,T], pre_parsing [B,T,pre],
         upos, xpos, attrs, aupos, axpos, aattrs) as float32 device tensors."""
@@ -586,6 +589,7 @@ class Parser(_HipNet):
         return (r["arc_logits"], pre, r["upos_logits"], xpos, attrs, aux[:, :, :n_u], aux[:, :, n_u:n_u + n_x],
                 aux[:, :, n_u + n_x:n_u + n_x + n_a])
 
+    @hip.on_device
     def _get_labels(self, labels, heads):
         """reference: parser.py:218-233.  `labels` = pre_parsing as returned by forward (the
         batch it came from must be the last one given to forward), `heads` = list of arrays."""
@@ -604,10 +608,12 @@ class Parser(_HipNet):
         logits, _ = self._label_scores(bt, pp, pp_w, bt["_heads"])
         return logits
 
+    @hip.on_device
     def decode_batch(self, X):
         """One batch of `process` on the device: everything up to the five int32 result arrays."""
         return self.decode_batch_prepared(self._prepare(X))
 
+    @hip.on_device
     def decode_batch_prepared(self, bt):
         """Single-stream, in-order execution on the current stream (tests / forward-style use);
         returns device tensors (views into the workspace, valid until the next batch)."""
@@ -616,6 +622,7 @@ class Parser(_HipNet):
     # ---- pipelined execution: GEMM-heavy phase of batch i+1 overlaps the latency-bound phase of i ----
     N_SLOTS = 3
 
+    @hip.on_device
     def submit(self, bt):
         """Enqueue one prepared batch on three HIP streams, one per stage: (1) char/word CNNs and tag
         heads (GEMMs that fill all CUs), (2) BiLSTM, pre_parsing and the arc scorer (a few persistent
@@ -628,9 +635,15 @@ class Parser(_HipNet):
             self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
             self._slot_free = [None] * self.N_SLOTS
             self._host_res = [None] * self.N_SLOTS
+            self._slot_busy = [False] * self.N_SLOTS
             self._n_submitted = 0
             self._buf.streams = self._streams
         slot = self._n_submitted % self.N_SLOTS
+        if self._slot_busy[slot]:
+            # the slot's pinned result buffer is still waiting to be read by `collect`: a fourth batch in
+            # flight would let its D->H copy overwrite results the host has not taken yet
+            raise hip.CubeHipError("Parser.submit: %d batches are in flight, collect() the oldest first" % self.N_SLOTS)
+        self._slot_busy[slot] = True
         self._n_submitted += 1
         s1, s2, s3 = self._streams
         cur = torch.cuda.current_stream()
@@ -672,7 +685,17 @@ class Parser(_HipNet):
         B, L = ticket["B"], ticket["L"]
         host = self._host_res[ticket["slot"]]
         n = 5 * B * L
-        return host[:n].view(5, B, L).numpy().copy(), host[n:n + B].numpy().copy()
+        out = host[:n].view(5, B, L).numpy().copy(), host[n:n + B].numpy().copy()
+        self._slot_busy[ticket["slot"]] = False  # only now may the slot's next batch overwrite the pinned buffer
+        return out
+
+    def _drain(self):
+        """Forget batches that were submitted and never collected (an exception between submit and collect):
+        wait for the stage streams, free every slot."""
+        if self._streams is not None:
+            for st in self._streams:
+                st.synchronize()
+            self._slot_busy = [False] * self.N_SLOTS
 
     def _write_back(self, batch, start, res, status):
         """parser.py:432-446: ids -> strings, into the Document."""
@@ -695,6 +718,7 @@ class Parser(_HipNet):
         """batches: iterable of (list of Sentence, position label for error messages); two deep in
         flight; results are written into the Sentence objects."""
         collate = collate or self._collate
+        self._drain()
         pending = None
         for batch, start in batches:
             X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
@@ -706,6 +730,7 @@ class Parser(_HipNet):
         if pending is not None:
             self._write_back(pending[0], pending[1], *self.collect(pending[2]))
 
+    @hip.on_device
     def process_bucketed(self, doc, collate, max_tokens=8192):
         """Throughput mode for ragged documents: sentences sorted by length and
         packed into batches of at most `max_tokens` padded positions, results written back in place.
@@ -721,6 +746,7 @@ class Parser(_HipNet):
         self._run_batches(([sents[i] for i in idx], int(idx[0])) for idx in groups)
         return doc
 
+    @hip.on_device
     def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=8192):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
         head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined

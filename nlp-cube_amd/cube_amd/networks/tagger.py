@@ -33,6 +33,7 @@ class Tagger(_HipNet):
         return out
 
     # ---- reference API ---------------------------------------------------------------------
+    @hip.on_device
     def forward(self, X):
         """reference: tagger.py:91-162.  Returns (upos, xpos, attrs, aupos, axpos, aattrs) logits
         [B, L, n] as float32 device tensors."""
@@ -46,6 +47,7 @@ class Tagger(_HipNet):
         return (r["upos_logits"], xpos, attrs, aux[:, :, :n_u], aux[:, :, n_u:n_u + n_x],
                 aux[:, :, n_u + n_x:n_u + n_x + n_a])
 
+    @hip.on_device
     def tag_batch(self, X):
         """One batch of `process` on the device: -> int32 [3, B, L] = upos, xpos, attrs ids (host)."""
         bt = self._prepare(X)
@@ -59,6 +61,7 @@ class Tagger(_HipNet):
         r["packed"] = packed
         return r
 
+    @hip.on_device
     def process(self, doc, collate, upos=True, xpos=True, attrs=True, batch_size=32, num_workers=4, merge=True,
                 max_tokens=8192):
         """reference: tagger.py:288-329 — in-order batches; fills upos / xpos / attrs of every word.

@@ -31,6 +31,7 @@ class Tokenizer(_HipNet):
         self._char_layers = 3  # WordGram default (tokenizer.py:49, modules.py:426)
         self._max_seq_len = max_seq_len
 
+    @hip.on_device
     def _prepare(self, X):
         """reference-format batch dict (TokenCollate*.collate_fn) -> device index arrays + embeddings."""
         self._require_gpu()
@@ -119,10 +120,12 @@ class Tokenizer(_HipNet):
                  n_valid=q["n_valid"], stream=st)
         return logits.view(B, T, q["n_valid"])
 
+    @hip.on_device
     def forward(self, batch):
         """-> logits f32 [B, T, 5] on the device (tokenizer.py:70-127)."""
         return self._logits(self._prepare(batch))
 
+    @hip.on_device
     def process(self, raw_text, collate, batch_size=32, num_workers=4, lang_id=0, dataset=None):
         """reference: tokenizer.py:224-304.  `collate` supplies `get_tokens(text)` and `collate_fn(examples)`
         (the reference's TokenCollate classes); `dataset` defaults to the reference's TokenDatasetLive

@@ -176,8 +176,9 @@ class ChuLiuEdmondsDecoder:
         status = torch.empty((B,), dtype=torch.int32, device=probs.device)
         nbytes = lib.cube_mst_workspace_bytes(B, L)
         ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=probs.device)
-        hip.check(lib.cube_mst_decode(probs.data_ptr(), lens.data_ptr(), B, L, heads.data_ptr(), status.data_ptr(),
-                                      ws.data_ptr(), ws.numel() * 8, hip.stream_handle()), "cube_mst_decode")
+        with torch.cuda.device(probs.device):  # launch on the stream of the device that holds the scores
+            hip.check(lib.cube_mst_decode(probs.data_ptr(), lens.data_ptr(), B, L, heads.data_ptr(), status.data_ptr(),
+                                          ws.data_ptr(), ws.numel() * 8, hip.stream_handle()), "cube_mst_decode")
         return heads, status
 
     def decode(self, score, lens):
