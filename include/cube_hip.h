@@ -197,6 +197,21 @@ size_t cube_mst_workspace_bytes(int B, int L);
 int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L,
                     int32_t* heads, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* cube_mst_decode for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * cube_mst_decode without the workspace: the task list, candidate trees and scores live in a built-in
+ * device array of CUBE_MST_NOALLOC_BYTES that every GPU the library runs on holds until the process
+ * ends.  Calls with cube_mst_workspace_bytes(B, L) > CUBE_MST_NOALLOC_BYTES are refused (CUBE_ERR_ARG):
+ * that covers B*L <= 8192 padded tokens up to L = 94 (longer sentences keep their score matrices in the
+ * workspace and need cube_mst_decode).  The call allocates and frees nothing.  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (two streams, two threads) race — serialise them.
+ * cube_init() resolves the array's address for the CURRENT device (once per device; the first
+ * cube_mst_decode_noalloc on a device does the same if it was not called — call it before a graph
+ * capture starts).                                                                               */
+#define CUBE_MST_NOALLOC_BYTES (4u << 20)
+int cube_init(void);
+int cube_mst_decode_noalloc(const float* probs, const int32_t* lens, int B, int L,
+                            int32_t* heads, int32_t* status, void* stream);
 
 /* Label scores for the decoded heads.  hl bf16 [B*T, ld_hl]: x1 = cols [0, D), x2 = cols
  * [col_x2, col_x2+D) (each with its constant-1 column inside D), D % 32 == 0.

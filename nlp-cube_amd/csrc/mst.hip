@@ -580,3 +580,52 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
   if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
   return mst_decode_impl(probs, lens, B, L, heads, status, workspace, (hipStream_t)stream);
 }
+
+// ---- the entry point that allocates nothing (include/cube_hip.h) -----------------------------------
+// The decoder's workspace (task list, candidate trees and scores) lives in a file-scope device array
+// instead of caller memory.  Every GPU the library runs on holds its own copy of the array at its own
+// address until the process ends; in host code the array's NAME is only a stand-in for the symbol, so the
+// address is asked for once per device (cube_init, or the first call on that device) and kept.
+static __device__ __align__(256) unsigned char scratch[CUBE_MST_NOALLOC_BYTES];
+
+namespace {
+std::atomic<void*> scratch_ptr[CUBE_MAX_DEVICES] = {};
+
+// device address of `scratch` on the CURRENT device (nullptr + error text on failure)
+void* mst_scratch() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CUBE_MAX_DEVICES) {
+    cube_set_error("cube_init: no current HIP device (or device index >= %d)", CUBE_MAX_DEVICES);
+    return nullptr;
+  }
+  void* p = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p) {
+    cube_set_error("cube_init: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    return nullptr;
+  }
+  scratch_ptr[dev].store(p, std::memory_order_release);  // racing threads store the same address
+  return p;
+}
+}  // namespace
+
+extern "C" int cube_init(void) {
+  CUBE_ENTRY();
+  return mst_scratch() ? CUBE_OK : CUBE_ERR_LAUNCH;
+}
+
+extern "C" int cube_mst_decode_noalloc(const float* probs, const int32_t* lens, int B, int L, int32_t* heads,
+                                       int32_t* status, void* stream) {
+  CUBE_ENTRY();
+  if (B <= 0 || L <= 0) return CUBE_OK;
+  if (!probs || !lens || !heads || !status) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: null pointer");
+  if (L + 1 > MST_MAX_N_GLOBAL)
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
+  if (mst_ws_bytes(B, L) > (size_t)CUBE_MST_NOALLOC_BYTES)
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: B=%d x L=%d needs %zu bytes of scratch, the built-in buffer holds %zu "
+              "(use cube_mst_decode with a caller workspace)", B, L, mst_ws_bytes(B, L), (size_t)CUBE_MST_NOALLOC_BYTES);
+  void* ws = mst_scratch();  // the per-device address, never the array's name
+  if (!ws) return CUBE_ERR_LAUNCH;
+  return mst_decode_impl(probs, lens, B, L, heads, status, ws, (hipStream_t)stream);
+}

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 8  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 9  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -105,6 +105,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     "cube_mst_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cube_mst_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cube_init": (c_int, []),
+    "cube_mst_decode_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cube_label_score": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cube_lemma_attend": (c_int, [ctypes.POINTER(LemmaAttendArgs), c_void_p]),

@@ -122,8 +122,10 @@ class _HipNet:
             # the reference defaults to 'cpu'; this implementation has no CPU path
             self._device = device
             return self
-        hip.load()
+        lib = hip.load()
         self._device = device
+        with torch.cuda.device(device):
+            hip.check(lib.cube_init(), "cube_init")  # per-device set-up of the library (include/cube_hip.h)
         if self._pk_cpu is not None:
             if self.precision not in ("bf16x3", "bf16"):
                 raise ValueError("precision must be 'bf16x3' or 'bf16'")
