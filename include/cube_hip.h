@@ -15,6 +15,7 @@
  *                           parser.py:140-154), unpack() (utils.py:17-32)
  *   cube_masked_mean        WordGram masked mean (modules.py:480-483)
  *   cube_char_conv0_lookup  WordGram embeddings + first ConvNorm/BatchNorm/gate (modules.py:451-472)
+ *   cube_split_f32          the fp32 -> operand-plane cast of the external embeddings (parser.py:130-136)
  *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197; tagger.py:118-119)
  *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
  *   cube_bilstm_recurrent   torch.lstm recurrence, 1 layer, both directions (parser.py:201)
@@ -31,6 +32,7 @@
  */
 #ifndef CUBE_HIP_H
 #define CUBE_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -171,6 +173,11 @@ int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const 
 int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K,
                     void* dst_a, void* dst_a_lo, int ld_a, int col_a,
                     void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream);
+
+/* hi[i] = bf16(x[i]) (round to nearest even), lo[i] = bf16(x[i] - hi[i]) (lo may be NULL): the hi/lo planes of
+ * an fp32 tensor — the external embeddings of a batch (parser.py:130-131: x_word_embeddings arrive as fp32
+ * from the LM helper, lm.py:199-208).  n % 4 == 0.                                                        */
+int cube_split_f32(const float* x, size_t n, void* hi, void* lo, void* stream);
 
 /* out[r] = first index of the maximum of x[r, col0 .. col0+n)   (x f32 [M, ld])             */
 int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream);

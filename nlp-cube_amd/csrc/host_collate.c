@@ -120,15 +120,682 @@ static PyObject* fill_ragged(PyObject* self, PyObject* args) {
   Py_RETURN_NONE;
 }
 
+/* ======================================================================================================
+ * featurize / write_back: the whole host side of one batch in two calls.
+ *
+ * featurize = MorphoCollate.collate_fn (reference cube/networks/utils.py:232-330) followed by the host half
+ * of Parser._prepare (cube_amd/networks/parser.py: word-length groups of the ragged character CNN, the packed
+ * int32 index upload, the external embeddings scattered to their padded [B*L, Epad] rows) in one pass over
+ * the Sentence / Word objects, without the reference-format int64 tensors in between.  The arrays are
+ * bit-identical to those of the Python path (tests/test_host.py).  write_back = the loop of
+ * Parser.process that stores head / label / upos / xpos / attrs into the words (parser.py:432-446).
+ * Words whose class keeps these attributes in __slots__ (cube_amd.io_utils.objects.Word) are read and
+ * written through the slot offsets; any other object (the reference's own Word) through getattr / setattr.
+ * ====================================================================================================== */
+#include <structmember.h>
+#include <pthread.h>
+#include "../../include/cube_hip.h" /* cube_conv_groups, CUBE_MAX_CONV_GROUPS */
+
+enum { F_WORD = 0, F_EMB, F_HEAD, F_LABEL, F_UPOS, F_XPOS, F_ATTRS, F_COUNT };
+static const char* const FIELD_NAMES[F_COUNT] = {"word", "emb", "head", "label", "upos", "xpos", "attrs"};
+static PyObject* field_str[F_COUNT];
+static PyObject *str_words, *str_lang_id, *str_lower;
+
+typedef struct {
+  PyTypeObject* tp;
+  Py_ssize_t off[F_COUNT]; /* slot offsets, -1 = use getattr / setattr */
+} WordLayout;
+
+static void word_layout(PyTypeObject* tp, WordLayout* wl) {
+  wl->tp = tp;
+  for (int f = 0; f < F_COUNT; ++f) {
+    wl->off[f] = -1;
+    PyObject* d = tp->tp_dict ? PyDict_GetItem(tp->tp_dict, field_str[f]) : NULL; /* borrowed; the class's own slots only */
+    if (d && Py_TYPE(d) == &PyMemberDescr_Type) {
+      PyMemberDef* m = ((PyMemberDescrObject*)d)->d_member;
+      if (m && m->type == T_OBJECT_EX && !(m->flags & READONLY)) wl->off[f] = m->offset;
+    }
+  }
+}
+
+/* new reference, or NULL with an exception set */
+static inline PyObject* word_get(PyObject* w, WordLayout* wl, int f) {
+  if (Py_TYPE(w) != wl->tp) word_layout(Py_TYPE(w), wl);
+  if (wl->off[f] >= 0) {
+    PyObject* v = *(PyObject**)((char*)w + wl->off[f]);
+    if (v) {
+      Py_INCREF(v);
+      return v;
+    }
+    PyErr_SetObject(PyExc_AttributeError, field_str[f]);
+    return NULL;
+  }
+  return PyObject_GetAttr(w, field_str[f]);
+}
+
+/* pointer valid while the GIL is held and the word is not modified; *owned = 1 when it is a NEW reference
+ * (the getattr path: the value may be computed on the fly), which the caller must keep until it is done */
+static inline PyObject* word_peek(PyObject* w, WordLayout* wl, int f, int* owned) {
+  if (Py_TYPE(w) != wl->tp) word_layout(Py_TYPE(w), wl);
+  *owned = 0;
+  if (wl->off[f] >= 0) {
+    PyObject* v = *(PyObject**)((char*)w + wl->off[f]);
+    if (!v) PyErr_SetObject(PyExc_AttributeError, field_str[f]);
+    return v;
+  }
+  *owned = 1;
+  return PyObject_GetAttr(w, field_str[f]);
+}
+
+/* steals nothing; 0 on success */
+static inline int word_set(PyObject* w, WordLayout* wl, int f, PyObject* v) {
+  if (Py_TYPE(w) != wl->tp) word_layout(Py_TYPE(w), wl);
+  if (wl->off[f] >= 0) {
+    PyObject** slot = (PyObject**)((char*)w + wl->off[f]);
+    PyObject* old = *slot;
+    Py_INCREF(v);
+    *slot = v;
+    Py_XDECREF(old);
+    return 0;
+  }
+  return PyObject_SetAttr(w, field_str[f], v);
+}
+
+#include <time.h>
+static double g_t[8];
+static long g_calls;
+static inline double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* Grow-only scratch buffers of featurize.  The call holds the GIL from start to end, so it cannot overlap itself;
+ * keeping the buffers avoids a dozen malloc / mmap / page-fault / munmap rounds of 64..800 KB per batch. */
+enum { SC_SLOTS = 16 };
+static void* g_sc[SC_SLOTS];
+static size_t g_sc_cap[SC_SLOTS];
+static void* sc_alloc(int slot, size_t bytes, int zero) {
+  if (bytes == 0) bytes = 8;
+  if (g_sc_cap[slot] < bytes) {
+    free(g_sc[slot]);
+    size_t cap = bytes + bytes / 2 + 4096;
+    g_sc[slot] = malloc(cap);
+    g_sc_cap[slot] = g_sc[slot] ? cap : 0;
+    if (!g_sc[slot]) return NULL;
+  }
+  if (zero) memset(g_sc[slot], 0, bytes);
+  return g_sc[slot];
+}
+
+typedef struct {
+  const float* const* src; /* [rows] source vector of a row, NULL = pad row */
+  float* dst;
+  Py_ssize_t E, Epad, row0, row1;
+} EmbJob;
+
+static void* emb_worker(void* arg) {
+  EmbJob* j = (EmbJob*)arg;
+  for (Py_ssize_t r = j->row0; r < j->row1; ++r) {
+    float* d = j->dst + r * j->Epad;
+    const float* s = j->src[r];
+    if (r + 4 < j->row1 && j->src[r + 4]) {
+      const char* q = (const char*)j->src[r + 4];
+      for (Py_ssize_t o = 0; o < j->E * 4; o += 256) __builtin_prefetch(q + o);
+    }
+    if (s) {
+      memcpy(d, s, (size_t)j->E * 4);
+      if (j->Epad > j->E) memset(d + j->E, 0, (size_t)(j->Epad - j->E) * 4);
+    } else {
+      memset(d, 0, (size_t)j->Epad * 4);
+    }
+  }
+  return NULL;
+}
+
+#define FEAT_FAIL(...)                     \
+  do {                                     \
+    PyErr_Format(PyExc_ValueError, __VA_ARGS__); \
+    goto fail;                             \
+  } while (0)
+
+/* featurize(sentences, word2int, wid_cache, unk, cp_tab, root, n_layers, n_case, L, emb_out, emb_dims, groups_addr, n_threads, ints_out)
+ *   sentences : list of Sentence (attributes words: list of Word, lang_id: int)
+ *   word2int  : dict lower-cased word -> id;  wid_cache: dict raw token -> id (filled here);  unk: id of <UNK>
+ *   cp_tab    : C-contiguous int32 [2, top]: (char id, case id) by code point, -1 = not yet known
+ *   root      : 1 = every sentence gets a root row in front (parser), 0 = not (tagger)
+ *   n_layers  : gated layers of the character CNN;  n_case: > 0 = one combined id char * n_case + case per
+ *               position (first layer by table look-up), 0 = separate character and case arrays
+ *   L         : longest sentence of the batch (words)
+ *   emb_out   : tuple of K writable float32 buffers of >= B*L*Epad_k elements;  emb_dims: tuple of (E_k, Epad_k)
+ *   groups_addr: address of n_layers cube_conv_groups structs (ctypes array), filled here
+ *   ints_out  : writable int32 buffer that receives the packed index arrays
+ * -> (int32 elements written to ints_out, sizes tuple of 10 ints, N, W, rows tuple of n_layers+1 ints)
+ *    or a list of code points missing from cp_tab (the caller extends the table and calls again)
+ *    or an int: the number of int32 elements ints_out must hold (it was too small; the caller calls again). */
+static PyObject* featurize(PyObject* self, PyObject* args) {
+  PyObject *sents, *word2int, *wid_cache, *emb_out, *emb_dims, *ints_out;
+  PyArrayObject* cp_tab;
+  long unk;
+  int root, n_layers, n_case, n_threads;
+  Py_ssize_t L;
+  unsigned long long groups_addr;
+  if (!PyArg_ParseTuple(args, "O!O!O!lO!iiinO!O!KiO", &PyList_Type, &sents, &PyDict_Type, &word2int, &PyDict_Type, &wid_cache,
+                        &unk, &PyArray_Type, &cp_tab, &root, &n_layers, &n_case, &L, &PyTuple_Type, &emb_out,
+                        &PyTuple_Type, &emb_dims, &groups_addr, &n_threads, &ints_out))
+    return NULL;
+  if (PyArray_TYPE(cp_tab) != NPY_INT32 || PyArray_NDIM(cp_tab) != 2 || PyArray_DIM(cp_tab, 0) != 2 ||
+      !PyArray_IS_C_CONTIGUOUS(cp_tab)) {
+    PyErr_SetString(PyExc_ValueError, "featurize: cp_tab must be a C-contiguous int32 [2, top] array");
+    return NULL;
+  }
+  const Py_ssize_t K = PyTuple_GET_SIZE(emb_out);
+  if (PyTuple_GET_SIZE(emb_dims) != K || n_layers < 1 || n_layers > 16 || root < 0 || root > 1 || L < 1 || K > 64) {
+    PyErr_SetString(PyExc_ValueError, "featurize: bad n_layers / root / L / embedding arguments");
+    return NULL;
+  }
+  const Py_ssize_t top = PyArray_DIM(cp_tab, 1);
+  const int32_t* tab_char = (const int32_t*)PyArray_DATA(cp_tab);
+  const int32_t* tab_case = tab_char + top;
+  const Py_ssize_t B = PyList_GET_SIZE(sents);
+  const Py_ssize_t T = L + root;
+
+  /* everything that must be released at the end */
+  PyObject** wstr = NULL;   /* [N] the words' str objects (borrowed) */
+  PyObject** wemb = NULL;   /* references to drop at the end (values that came from getattr) */
+  int32_t *wlen = NULL, *wid = NULL, *sb = NULL, *si = NULL, *slen = NULL, *lang = NULL, *order = NULL, *cp_off = NULL;
+  const float** esrc = NULL;
+  Py_buffer ebuf[64];
+  Py_ssize_t n_ebuf = 0, n_wstr = 0, n_wemb = 0;
+  PyObject* missing = NULL;
+  PyObject* result = NULL;
+  Py_buffer ibuf;
+  int have_ibuf = 0;
+  WordLayout wl;
+  wl.tp = NULL;
+
+  Py_ssize_t E[64], Epad[64];
+  if (PyObject_GetBuffer(ints_out, &ibuf, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) goto fail;
+  have_ibuf = 1;
+  for (Py_ssize_t k = 0; k < K; ++k) {
+    PyObject* d = PyTuple_GET_ITEM(emb_dims, k);
+    if (!PyTuple_Check(d) || PyTuple_GET_SIZE(d) != 2) FEAT_FAIL("featurize: emb_dims must hold (E, Epad) pairs");
+    E[k] = PyLong_AsSsize_t(PyTuple_GET_ITEM(d, 0));
+    Epad[k] = PyLong_AsSsize_t(PyTuple_GET_ITEM(d, 1));
+    if (PyErr_Occurred() || E[k] < 1 || Epad[k] < E[k]) FEAT_FAIL("featurize: bad embedding sizes");
+    if (PyObject_GetBuffer(PyTuple_GET_ITEM(emb_out, k), &ebuf[k], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) goto fail;
+    ++n_ebuf;
+    if (ebuf[k].len < (Py_ssize_t)(B * L * Epad[k] * 4)) FEAT_FAIL("featurize: embedding buffer %zd is too small", k);
+  }
+
+  double t_start = now_s();
+  /* ---- pass 0: sizes */
+  slen = (int32_t*)sc_alloc(0, sizeof(int32_t) * (size_t)(B + 1), 0);
+  lang = (int32_t*)sc_alloc(1, sizeof(int32_t) * (size_t)(B + 1), 0);
+  if (!slen || !lang) { PyErr_NoMemory(); goto fail; }
+  Py_ssize_t N = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* s = PyList_GET_ITEM(sents, b);
+    PyObject* ws = PyObject_GetAttr(s, str_words);
+    if (!ws) goto fail;
+    if (!PyList_Check(ws)) { Py_DECREF(ws); FEAT_FAIL("featurize: sentence %zd: .words is not a list", b); }
+    const Py_ssize_t n = PyList_GET_SIZE(ws);
+    Py_DECREF(ws); /* the sentence keeps it alive */
+    if (n > L) FEAT_FAIL("featurize: sentence %zd has %zd words, L = %zd", b, n, L);
+    slen[b] = (int32_t)n;
+    N += n;
+    PyObject* lg = PyObject_GetAttr(s, str_lang_id);
+    if (!lg) goto fail;
+    const long lv = PyLong_AsLong(lg);
+    Py_DECREF(lg);
+    if (lv == -1 && PyErr_Occurred()) goto fail;
+    lang[b] = (int32_t)(lv + 1); /* utils.py:266: x_lang = lang_id + 1 */
+  }
+  if (N == 0) FEAT_FAIL("featurize: the batch holds no words");
+  wstr = (PyObject**)sc_alloc(2, sizeof(PyObject*) * (size_t)N, 0);
+  wemb = (PyObject**)sc_alloc(3, sizeof(PyObject*) * (size_t)(2 * N), 0); /* references taken on the getattr path */
+  wlen = (int32_t*)sc_alloc(4, sizeof(int32_t) * (size_t)N, 0);
+  wid = (int32_t*)sc_alloc(5, sizeof(int32_t) * (size_t)N, 0);
+  sb = (int32_t*)sc_alloc(6, sizeof(int32_t) * (size_t)N, 0);
+  si = (int32_t*)sc_alloc(7, sizeof(int32_t) * (size_t)N, 0);
+  order = (int32_t*)sc_alloc(8, sizeof(int32_t) * (size_t)N, 0);
+  cp_off = (int32_t*)sc_alloc(9, sizeof(int32_t) * (size_t)(N + 1), 0);
+  esrc = (const float**)sc_alloc(10, sizeof(float*) * (size_t)(B * L * (K ? K : 1)), 1); /* NULL = pad row */
+  if (!wstr || !wemb || !wlen || !wid || !sb || !si || !order || !cp_off || !esrc) { PyErr_NoMemory(); goto fail; }
+
+  g_t[0] += now_s() - t_start; t_start = now_s();
+  /* ---- pass 1: the objects, in sweeps over all words with the next level's memory prefetched a few words
+   * ahead (a Word, its str, its emb list, the list's item array, the arrays and their data are separate heap
+   * objects: walked word by word, every step is a cache miss).  The GIL is held throughout and nothing below
+   * runs Python code, so borrowed pointers stay valid until the references are taken in sweep C. */
+  enum { PF = 12 };
+  Py_ssize_t i = 0, total_chars = 0, W = 0;
+  {
+    PyObject** wobj = (PyObject**)sc_alloc(11, sizeof(PyObject*) * (size_t)N, 0);
+    PyObject** wel = (PyObject**)sc_alloc(12, sizeof(PyObject*) * (size_t)N, 0);
+    PyObject*** witems = (PyObject***)sc_alloc(13, sizeof(PyObject**) * (size_t)N, 0);
+    int bad = (!wobj || !wel || !witems);
+    if (bad) PyErr_NoMemory();
+    /* sweep A: the Word objects of every sentence */
+    for (Py_ssize_t b = 0; !bad && b < B; ++b) {
+      PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+      if (!ws) { bad = 1; break; }
+      if (!PyList_Check(ws) || PyList_GET_SIZE(ws) != slen[b]) {
+        Py_DECREF(ws);
+        PyErr_Format(PyExc_ValueError, "featurize: sentence %zd changed", b);
+        bad = 1;
+        break;
+      }
+      for (Py_ssize_t j = 0; j < slen[b]; ++j, ++i) {
+        wobj[i] = PyList_GET_ITEM(ws, j);
+        sb[i] = (int32_t)b;
+        si[i] = (int32_t)j;
+      }
+      Py_DECREF(ws); /* the sentence keeps its list */
+    }
+    /* sweep B: the str and the emb list of every word (slot reads: borrowed; getattr results are kept) */
+    for (Py_ssize_t w = 0; !bad && w < N; ++w) {
+      if (w + PF < N) { __builtin_prefetch(wobj[w + PF]); __builtin_prefetch((char*)wobj[w + PF] + 64); }
+      int owned = 0;
+      PyObject* t = word_peek(wobj[w], &wl, F_WORD, &owned);
+      if (!t) { bad = 1; break; }
+      wstr[w] = t;
+      if (owned) wemb[n_wemb++] = t; /* `wemb` doubles as the list of references to drop at the end */
+      if (K > 0) {
+        PyObject* el = word_peek(wobj[w], &wl, F_EMB, &owned);
+        if (!el) { bad = 1; break; }
+        wel[w] = el;
+        if (owned) wemb[n_wemb++] = el;
+      }
+    }
+    /* sweep C: the strings: length, word id through the raw-token cache (lower-cased look-up, utils.py:284-289) */
+    for (Py_ssize_t w = 0; !bad && w < N; ++w) {
+      if (w + PF < N) {
+        __builtin_prefetch(wstr[w + PF]);
+        if (K > 0) __builtin_prefetch(wel[w + PF]);
+      }
+      PyObject* t = wstr[w];
+      if (!PyUnicode_Check(t) || PyUnicode_READY(t) != 0) {
+        PyErr_Format(PyExc_ValueError, "featurize: word %d of sentence %d is not a str", (int)si[w], (int)sb[w]);
+        bad = 1;
+        break;
+      }
+      const Py_ssize_t len = PyUnicode_GET_LENGTH(t);
+      wlen[w] = (int32_t)len;
+      if (len > W) W = len;
+      cp_off[w] = (int32_t)total_chars;
+      total_chars += len;
+      PyObject* id = PyDict_GetItemWithError(wid_cache, t); /* borrowed */
+      if (!id) {
+        if (PyErr_Occurred()) { bad = 1; break; }
+        PyObject* lo = PyObject_CallMethodNoArgs(t, str_lower);
+        if (!lo) { bad = 1; break; }
+        id = PyDict_GetItemWithError(word2int, lo);
+        Py_DECREF(lo);
+        if (!id && PyErr_Occurred()) { bad = 1; break; }
+        long v = id ? PyLong_AsLong(id) : unk;
+        if (v == -1 && PyErr_Occurred()) { bad = 1; break; }
+        wid[w] = (int32_t)v;
+        if (PyDict_GET_SIZE(wid_cache) > (1 << 20)) PyDict_Clear(wid_cache);
+        PyObject* pv = PyLong_FromLong(v);
+        if (!pv || PyDict_SetItem(wid_cache, t, pv) != 0) { Py_XDECREF(pv); bad = 1; break; }
+        Py_DECREF(pv);
+      } else {
+        const long v = PyLong_AsLong(id);
+        if (v == -1 && PyErr_Occurred()) { bad = 1; break; }
+        wid[w] = (int32_t)v;
+      }
+    }
+    if (!bad && K > 0) {
+      int good = 1;
+      /* sweep D: the emb lists -> their item arrays */
+      for (Py_ssize_t w = 0; good && w < N; ++w) {
+        PyObject* el = wel[w];
+        if (!(PyList_Check(el) || PyTuple_Check(el)) || PySequence_Fast_GET_SIZE(el) != K) { good = 0; break; }
+        witems[w] = PySequence_Fast_ITEMS(el);
+        __builtin_prefetch(witems[w]); /* the item array, read by sweep E */
+      }
+      /* sweep E: the array objects, level by level (borrowed: the GIL is held until the copies are done) */
+      PyObject** arr = (PyObject**)wobj; /* the Word pointers are no longer needed */
+      for (Py_ssize_t k = 0; good && k < K; ++k) {
+        for (Py_ssize_t w = 0; w < N; ++w) {
+          arr[w] = witems[w][k];
+          __builtin_prefetch((char*)arr[w] + 16); /* the PyArrayObject header, read by the next loop */
+        }
+        for (Py_ssize_t w = 0; w < N; ++w) {
+          PyObject* a = arr[w];
+          if (!PyArray_Check(a) || PyArray_TYPE((PyArrayObject*)a) != NPY_FLOAT32 || PyArray_NDIM((PyArrayObject*)a) != 1 ||
+              PyArray_DIM((PyArrayObject*)a, 0) != E[k] || !PyArray_IS_C_CONTIGUOUS((PyArrayObject*)a)) {
+            good = 0;
+            break;
+          }
+          esrc[(size_t)k * B * L + (size_t)sb[w] * L + si[w]] = (const float*)PyArray_DATA((PyArrayObject*)a);
+        }
+      }
+      if (!good) {
+        PyErr_SetString(PyExc_TypeError, "featurize: word.emb is not a list of contiguous float32 vectors of the model's sizes");
+        bad = 1;
+      }
+    }
+    if (bad) goto fail;
+  }
+  cp_off[N] = (int32_t)total_chars;
+
+  g_t[1] += now_s() - t_start; t_start = now_s();
+  /* ---- characters: code point -> (char id, case id); unknown code points go back to the caller */
+  {
+    int32_t* cps = (int32_t*)sc_alloc(14, sizeof(int32_t) * (size_t)(total_chars + 1), 0);
+    if (!cps) { PyErr_NoMemory(); goto fail; }
+    Py_ssize_t q = 0;
+    for (Py_ssize_t w = 0; w < N; ++w) {
+      const int kind = PyUnicode_KIND(wstr[w]);
+      const void* data = PyUnicode_DATA(wstr[w]);
+      for (Py_ssize_t c = 0; c < wlen[w]; ++c) {
+        const Py_UCS4 cp = PyUnicode_READ(kind, data, c);
+        cps[q++] = (int32_t)cp;
+        if ((Py_ssize_t)cp >= top || tab_char[cp] < 0) {
+          if (!missing) missing = PyList_New(0);
+          PyObject* v = missing ? PyLong_FromLong((long)cp) : NULL;
+          if (!v || PyList_Append(missing, v) != 0) { Py_XDECREF(v); goto fail; }
+          Py_DECREF(v);
+        }
+      }
+    }
+    if (missing) {
+      result = missing;
+      missing = NULL;
+      goto done;
+    }
+
+    /* ---- word-length groups of the ragged character CNN (Parser._char_layout) */
+    const int MAXG = CUBE_MAX_CONV_GROUPS;
+    int cnt[CUBE_MAX_CONV_GROUPS] = {0}, gmax_key[CUBE_MAX_CONV_GROUPS] = {0}, start_key[CUBE_MAX_CONV_GROUPS + 1];
+    for (Py_ssize_t w = 0; w < N; ++w) {
+      int key = wlen[w] < 1 ? 1 : wlen[w];
+      if (key > MAXG - 1) key = MAXG - 1;
+      cnt[key]++;
+      const int l1 = wlen[w] < 1 ? 1 : wlen[w];
+      if (l1 > gmax_key[key]) gmax_key[key] = l1;
+    }
+    start_key[0] = 0;
+    for (int k = 0; k < MAXG; ++k) start_key[k + 1] = start_key[k] + cnt[k];
+    {
+      int fill[CUBE_MAX_CONV_GROUPS];
+      for (int k = 0; k < MAXG; ++k) fill[k] = start_key[k];
+      for (Py_ssize_t w = 0; w < N; ++w) { /* stable counting sort */
+        int key = wlen[w] < 1 ? 1 : wlen[w];
+        if (key > MAXG - 1) key = MAXG - 1;
+        order[fill[key]++] = (int32_t)w;
+      }
+    }
+    int G = 0, gkey[CUBE_MAX_CONV_GROUPS];
+    for (int k = 0; k < MAXG; ++k)
+      if (cnt[k]) gkey[G++] = k;
+    const int n = n_layers;
+    /* seq[k][g], rows_g[k][g], row0[k][g] for layouts k = 0..n */
+    long seq[17][CUBE_MAX_CONV_GROUPS], row0[17][CUBE_MAX_CONV_GROUPS], rows_total[17];
+    for (int k = 0; k <= n; ++k) {
+      long run = 0;
+      for (int g = 0; g < G; ++g) {
+        long sq = gmax_key[gkey[g]] + 2L * (n - k);
+        if (sq > W) sq = W;
+        seq[k][g] = sq;
+        row0[k][g] = run;
+        run += sq * cnt[gkey[g]];
+      }
+      rows_total[k] = run;
+    }
+    cube_conv_groups* cg = (cube_conv_groups*)(uintptr_t)groups_addr;
+    for (int l = 0; l < n; ++l) {
+      cg[l].n = G;
+      for (int g = 0; g < G; ++g) {
+        cg[l].row0_in[g] = (int)row0[l][g];
+        cg[l].n_rows[g] = (int)(seq[l][g] * cnt[gkey[g]]);
+        cg[l].seq_in[g] = (int)seq[l][g];
+        cg[l].row0_out[g] = (int)row0[l + 1][g];
+        cg[l].seq_out[g] = (int)seq[l + 1][g];
+        cg[l].word0[g] = start_key[gkey[g]];
+      }
+    }
+
+    /* ---- the packed int32 upload (order and 4-element alignment of Parser._prepare) */
+    const Py_ssize_t n_char = rows_total[0];
+    Py_ssize_t sizes[10] = {n_char, n_case > 0 ? 0 : n_char, N, N, N, B * T, B * T, B, B, (Py_ssize_t)n * N};
+    Py_ssize_t offs[11];
+    offs[0] = 0;
+    for (int p = 0; p < 10; ++p) offs[p + 1] = offs[p] + (sizes[p] + 3) / 4 * 4;
+    if ((Py_ssize_t)(ibuf.len / 4) < offs[10]) { /* the caller's index buffer is too small: tell it the size, it calls again */
+      result = PyLong_FromSsize_t(offs[10]);
+      goto done;
+    }
+    int32_t* P = (int32_t*)ibuf.buf;
+    memset(P, 0, (size_t)offs[10] * 4);
+    {
+      int32_t* pc = P + offs[0];
+      int32_t* pk = P + offs[1];
+      Py_ssize_t r = 0;
+      for (int g = 0; g < G; ++g) {
+        const long q0 = seq[0][g];
+        for (int a = start_key[gkey[g]]; a < start_key[gkey[g] + 1]; ++a) {
+          const int w = order[a];
+          const int32_t* c = cps + cp_off[w];
+          const long len = wlen[w];
+          for (long pos = 0; pos < q0; ++pos, ++r) {
+            int32_t ch = 0, ca = 0;
+            if (pos < len) { ch = tab_char[c[pos]]; ca = tab_case[c[pos]]; }
+            if (n_case > 0) pc[r] = ch * n_case + ca;
+            else { pc[r] = ch; pk[r] = ca; }
+          }
+        }
+      }
+    }
+    {
+      int32_t *p_lang = P + offs[2], *p_len = P + offs[3], *p_rowmap = P + offs[4], *p_widx = P + offs[5];
+      int32_t *p_lrows = P + offs[6], *p_root = P + offs[7], *p_lens = P + offs[8], *p_wrows = P + offs[9];
+      for (Py_ssize_t a = 0; a < N; ++a) {
+        const int w = order[a];
+        p_lang[a] = lang[sb[w]];
+        p_len[a] = wlen[w];
+        p_rowmap[a] = (int32_t)(sb[w] * T + si[w] + root);
+      }
+      for (Py_ssize_t w = 0; w < N; ++w) p_widx[sb[w] * T + si[w] + root] = wid[w];
+      for (Py_ssize_t b = 0; b < B; ++b) {
+        for (Py_ssize_t t = 0; t < T; ++t) p_lrows[b * T + t] = lang[b];
+        p_root[b] = (int32_t)(b * T);
+        p_lens[b] = slen[b];
+      }
+      for (int l = 0; l < n; ++l)
+        for (int g = 0; g < G; ++g) {
+          const int s0 = start_key[gkey[g]];
+          for (int a = s0; a < start_key[gkey[g] + 1]; ++a)
+            p_wrows[(Py_ssize_t)l * N + a] = (int32_t)(row0[l + 1][g] + (long)(a - s0) * seq[l + 1][g]);
+        }
+    }
+
+    g_t[2] += now_s() - t_start; t_start = now_s();
+    /* ---- external embeddings -> padded [B*L, Epad] rows, on worker threads */
+    if (K > 0) {
+      int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+      const Py_ssize_t rows = B * L;
+      if (rows * Epad[0] < (1 << 16)) nt = 1;
+      EmbJob jobs[16 * 64];
+      pthread_t th[16 * 64];
+      int nj = 0;
+      for (Py_ssize_t k = 0; k < K; ++k)
+        for (int t = 0; t < nt; ++t) {
+          EmbJob* j = &jobs[nj++];
+          j->src = esrc + (size_t)k * B * L;
+          j->dst = (float*)ebuf[k].buf;
+          j->E = E[k];
+          j->Epad = Epad[k];
+          j->row0 = rows * t / nt;
+          j->row1 = rows * (t + 1) / nt;
+          if (nj >= 16 * 64) break;
+        }
+      /* the GIL stays held: the vectors are borrowed, and nothing else of this process's Python may run meanwhile */
+      if (nj == 1) {
+        emb_worker(&jobs[0]);
+      } else {
+        int started = 0;
+        for (; started < nj - 1; ++started)
+          if (pthread_create(&th[started], NULL, emb_worker, &jobs[started]) != 0) break;
+        for (int t = started; t < nj; ++t) emb_worker(&jobs[t]); /* the caller's thread takes the rest */
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+      }
+    }
+
+    g_t[3] += now_s() - t_start; t_start = now_s();
+    ++g_calls;
+    PyObject* rows_t = PyTuple_New(n + 1);
+    PyObject* sizes_t = PyTuple_New(10);
+    if (!rows_t || !sizes_t) { Py_XDECREF(rows_t); Py_XDECREF(sizes_t); goto fail; }
+    for (int k = 0; k <= n; ++k) PyTuple_SET_ITEM(rows_t, k, PyLong_FromLong(rows_total[k]));
+    for (int p = 0; p < 10; ++p) PyTuple_SET_ITEM(sizes_t, p, PyLong_FromSsize_t(sizes[p]));
+    result = Py_BuildValue("(nNnnN)", offs[10], sizes_t, N, W, rows_t);
+  }
+  goto done;
+fail:
+  Py_XDECREF(missing);
+  result = NULL;
+done:
+  if (have_ibuf) PyBuffer_Release(&ibuf);
+  for (Py_ssize_t k = 0; k < n_ebuf; ++k) PyBuffer_Release(&ebuf[k]);
+  if (wemb) for (Py_ssize_t w = 0; w < n_wemb; ++w) Py_XDECREF(wemb[w]);
+  return result;
+}
+
+/* timing() -> (calls, seconds in: sizes pass, object pass, index arrays, embedding copies) since the last call */
+static PyObject* timing(PyObject* self, PyObject* args) {
+  PyObject* r = Py_BuildValue("(ldddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3]);
+  g_calls = 0;
+  for (int i = 0; i < 8; ++i) g_t[i] = 0.0;
+  return r;
+}
+
+/* geometry(sentences) -> (int32 [n] words per sentence, int32 [n] longest word per sentence): what decides the
+ * padding of a reference batch (longest sentence, longest word), for merging reference batches of equal geometry
+ * (cube_amd/sharding.py) without a Python-level pass over every word. */
+static PyObject* geometry(PyObject* self, PyObject* args) {
+  PyObject* sents;
+  if (!PyArg_ParseTuple(args, "O!", &PyList_Type, &sents)) return NULL;
+  const Py_ssize_t n = PyList_GET_SIZE(sents);
+  npy_intp dims[1] = {(npy_intp)n};
+  PyArrayObject* a_len = (PyArrayObject*)PyArray_ZEROS(1, dims, NPY_INT32, 0);
+  PyArrayObject* a_wmax = (PyArrayObject*)PyArray_ZEROS(1, dims, NPY_INT32, 0);
+  if (!a_len || !a_wmax) { Py_XDECREF(a_len); Py_XDECREF(a_wmax); return NULL; }
+  int32_t* pl = (int32_t*)PyArray_DATA(a_len);
+  int32_t* pw = (int32_t*)PyArray_DATA(a_wmax);
+  WordLayout wl;
+  wl.tp = NULL;
+  for (Py_ssize_t b = 0; b < n; ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws || !PyList_Check(ws)) {
+      if (ws) PyErr_SetString(PyExc_TypeError, "geometry: sentence.words is not a list");
+      Py_XDECREF(ws); Py_DECREF(a_len); Py_DECREF(a_wmax);
+      return NULL;
+    }
+    const Py_ssize_t m = PyList_GET_SIZE(ws);
+    pl[b] = (int32_t)m;
+    Py_ssize_t mx = 0;
+    for (Py_ssize_t j = 0; j < m; ++j) {
+      PyObject* t = word_get(PyList_GET_ITEM(ws, j), &wl, F_WORD);
+      if (!t || !PyUnicode_Check(t) || PyUnicode_READY(t) != 0) {
+        if (t) PyErr_SetString(PyExc_TypeError, "geometry: word.word is not a str");
+        Py_XDECREF(t); Py_DECREF(ws); Py_DECREF(a_len); Py_DECREF(a_wmax);
+        return NULL;
+      }
+      if (PyUnicode_GET_LENGTH(t) > mx) mx = PyUnicode_GET_LENGTH(t);
+      Py_DECREF(t);
+    }
+    pw[b] = (int32_t)mx;
+    Py_DECREF(ws);
+  }
+  return Py_BuildValue("(NN)", (PyObject*)a_len, (PyObject*)a_wmax);
+}
+
+/* write_back(sentences, res, tables): res C-contiguous int32 [5, B, L] = heads, labels, upos, xpos, attrs ids;
+ * tables = (labels, upos_list, xpos_list, attrs_list) lists of str.  Sets word.head (int) and the four strings
+ * of every word of every sentence (parser.py:432-446). */
+static PyObject* write_back(PyObject* self, PyObject* args) {
+  PyObject *sents, *tabs;
+  PyArrayObject* res;
+  if (!PyArg_ParseTuple(args, "O!O!O!", &PyList_Type, &sents, &PyArray_Type, &res, &PyTuple_Type, &tabs)) return NULL;
+  if (PyArray_TYPE(res) != NPY_INT32 || PyArray_NDIM(res) != 3 || PyArray_DIM(res, 0) != 5 || !PyArray_IS_C_CONTIGUOUS(res) ||
+      PyTuple_GET_SIZE(tabs) != 4) {
+    PyErr_SetString(PyExc_ValueError, "write_back: res must be C-contiguous int32 [5, B, L], tables a 4-tuple");
+    return NULL;
+  }
+  const Py_ssize_t B = PyArray_DIM(res, 1), L = PyArray_DIM(res, 2);
+  if (PyList_GET_SIZE(sents) != B) {
+    PyErr_SetString(PyExc_ValueError, "write_back: one result row per sentence expected");
+    return NULL;
+  }
+  PyObject* tab[4];
+  Py_ssize_t ntab[4];
+  for (int t = 0; t < 4; ++t) {
+    tab[t] = PyTuple_GET_ITEM(tabs, t);
+    if (!PyList_Check(tab[t])) {
+      PyErr_SetString(PyExc_ValueError, "write_back: the id -> string tables must be lists");
+      return NULL;
+    }
+    ntab[t] = PyList_GET_SIZE(tab[t]);
+  }
+  static const int field_of[4] = {F_LABEL, F_UPOS, F_XPOS, F_ATTRS};
+  const int32_t* R = (const int32_t*)PyArray_DATA(res);
+  WordLayout wl;
+  wl.tp = NULL;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws) return NULL;
+    if (!PyList_Check(ws) || PyList_GET_SIZE(ws) > L) {
+      Py_DECREF(ws);
+      PyErr_Format(PyExc_ValueError, "write_back: sentence %zd does not fit the result array", b);
+      return NULL;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(ws);
+    for (Py_ssize_t j = 0; j < n; ++j) {
+      PyObject* w = PyList_GET_ITEM(ws, j);
+      if (j + 8 < n) { __builtin_prefetch(PyList_GET_ITEM(ws, j + 8), 1); __builtin_prefetch((char*)PyList_GET_ITEM(ws, j + 8) + 64, 1); }
+      PyObject* h = PyLong_FromLong((long)R[(0 * B + b) * L + j]); /* small ints come from CPython's cache */
+      if (!h || word_set(w, &wl, F_HEAD, h) != 0) { Py_XDECREF(h); Py_DECREF(ws); return NULL; }
+      Py_DECREF(h);
+      for (int t = 0; t < 4; ++t) {
+        const int32_t id = R[((t + 1) * B + b) * L + j];
+        if (id < 0 || id >= ntab[t]) {
+          Py_DECREF(ws);
+          PyErr_Format(PyExc_IndexError, "write_back: id %d outside table %d", (int)id, t);
+          return NULL;
+        }
+        if (word_set(w, &wl, field_of[t], PyList_GET_ITEM(tab[t], id)) != 0) { Py_DECREF(ws); return NULL; }
+      }
+    }
+    Py_DECREF(ws);
+  }
+  Py_RETURN_NONE;
+}
+
+
 static PyMethodDef methods[] = {
     {"stack_rows", stack_rows, METH_VARARGS, "copy N equal-size contiguous buffers into one [N, size] buffer"},
     {"fill_ragged", fill_ragged, METH_VARARGS, "ragged int64 values -> zero-padded int64 [N, width] rows"},
+    {"featurize", featurize, METH_VARARGS, "Sentence objects -> packed index arrays + padded embedding rows of one batch"},
+    {"timing", timing, METH_NOARGS, "accumulated seconds per stage of featurize since the last call"},
+    {"geometry", geometry, METH_VARARGS, "words per sentence and longest word per sentence"},
+    {"write_back", write_back, METH_VARARGS, "result ids -> head / label / upos / xpos / attrs of every word"},
     {NULL, NULL, 0, NULL}};
 
-static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_cube_host", "host-side bulk copies of the featurisation", -1,
+static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_cube_host", "host side of the parser path: featurisation and write-back", -1,
                                     methods};
 
 PyMODINIT_FUNC PyInit__cube_host(void) {
   import_array();
+  for (int f = 0; f < F_COUNT; ++f) {
+    field_str[f] = PyUnicode_InternFromString(FIELD_NAMES[f]);
+    if (!field_str[f]) return NULL;
+  }
+  str_words = PyUnicode_InternFromString("words");
+  str_lang_id = PyUnicode_InternFromString("lang_id");
+  str_lower = PyUnicode_InternFromString("lower");
+  if (!str_words || !str_lang_id || !str_lower) return NULL;
   return PyModule_Create(&module);
 }

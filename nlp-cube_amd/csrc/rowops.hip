@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 9; }
+extern "C" int cube_abi_version(void) { return 10; }
 
 namespace {
 
@@ -460,5 +460,37 @@ extern "C" int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, 
   if (!x || !out || n <= 0 || col0 < 0 || col0 + n > ld) CUBE_FAIL(CUBE_ERR_ARG, "cube_argmax_rows: bad args");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, col0, n, M, out);
   CUBE_CHECK_LAUNCH("cube_argmax_rows");
+  return CUBE_OK;
+}
+
+// ---- fp32 -> bf16 hi (+ lo) planes: the external embeddings arrive from the host as fp32 rows
+namespace {
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, size_t n4, uint2* __restrict__ hi,
+                                                        uint2* __restrict__ lo) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    uint16_t h[4], l[4];
+    split_bf16(v.x, h[0], l[0]);
+    split_bf16(v.y, h[1], l[1]);
+    split_bf16(v.z, h[2], l[2]);
+    split_bf16(v.w, h[3], l[3]);
+    hi[i] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    if (lo) lo[i] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  }
+}
+}  // namespace
+
+extern "C" int cube_split_f32(const float* x, size_t n, void* hi, void* lo, void* stream) {
+  CUBE_ENTRY();
+  if (n == 0) return CUBE_OK;
+  if (!x || !hi) CUBE_FAIL(CUBE_ERR_ARG, "cube_split_f32: null pointer");
+  if (n % 4 || (uintptr_t)x % 16 || (uintptr_t)hi % 8 || (uintptr_t)lo % 8)
+    CUBE_FAIL(CUBE_ERR_ALIGN, "cube_split_f32: n must be a multiple of 4, x 16-byte and hi / lo 8-byte aligned");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, n4, (uint2*)hi,
+                     (uint2*)lo);
+  CUBE_CHECK_LAUNCH("cube_split_f32");
   return CUBE_OK;
 }

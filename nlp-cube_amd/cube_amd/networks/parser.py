@@ -25,7 +25,7 @@ import os
 import numpy as np
 import torch
 
-from cube_amd import hip
+from cube_amd import hip, host
 from cube_amd.networks import packing
 from cube_amd.networks.packing import p32, p128
 from cube_amd.networks.utils import MorphoCollate, MorphoDataset, ChuLiuEdmondsDecoder  # noqa: F401
@@ -171,12 +171,14 @@ class _HipNet:
         return _Ctx()
 
     # ---- batch preparation -----------------------------------------------------------------
-    @hip.on_device
-    def _prepare(self, X):
-        """reference-format batch dict (MorphoCollate.collate_fn) -> device index arrays.
-        One packed int32 upload + one (hi[, lo]) bf16 upload per LM layer."""
-        self._require_gpu()
-        dev = self._device
+    _PART_NAMES = ("char_idx", "case_idx", "lang_word", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
+                   "lens", "word_rows")
+
+    def _prepare_host(self, X):
+        """reference-format batch dict (MorphoCollate.collate_fn) -> the host half of a prepared batch:
+        one packed int32 array (the ten index arrays of `_PART_NAMES`, each padded to 4 elements), the
+        external embeddings scattered to their padded [B*L, Epad] fp32 rows, the ragged character-CNN
+        groups.  `_featurize` builds the same arrays straight from the Sentence objects in C."""
         x_sent = X["x_sent"].cpu().numpy()
         sl = X["x_sent_len"].cpu().numpy().astype(np.int64)
         x_word = X["x_word"].cpu().numpy()
@@ -194,7 +196,7 @@ class _HipNet:
         x_case = X["x_word_case"].cpu().numpy()
         char_idx = np.concatenate([x_word[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
         case_idx = np.concatenate([x_case[order[s:e], :q].reshape(-1) for s, e, q in ch["gather"]])
-        l0 = self._pk.get("char_l0")
+        l0 = self._pk_cpu.get("char_l0")
         if l0 is not None:  # layer 0 by table look-up: one (character, case) combination id per position
             char_idx, case_idx = char_idx * l0["n_case"] + case_idx, np.zeros(0, dtype=np.int64)
         parts = [
@@ -202,31 +204,147 @@ class _HipNet:
             (sb * T + si + root)[order], word_idx.reshape(-1), np.repeat(lang_sent, T), np.arange(B) * T, sl,
             ch["word_rows"].reshape(-1),
         ]
-        sizes = [p.size for p in parts]
+        sizes = [int(p.size) for p in parts]
         offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
         packed = np.zeros(int(offs[-1]), dtype=np.int32)
         for p, o, s in zip(parts, offs[:-1], sizes):
             packed[o:o + s] = p
-        ints = torch.from_numpy(packed).to(dev, non_blocking=True)
-        names = ("char_idx", "case_idx", "lang_word", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
-                 "lens", "word_rows")
-        bt = {n: ints[o:o + s] for n, o, s in zip(names, offs[:-1], sizes)}
         embs = []
-        dst = None if N == B * L else torch.from_numpy(sb * L + si).to(dev, non_blocking=True)
         for k, e in enumerate(X["x_word_embeddings"]):
-            # fp32 upload; padding to [B*L, Epad] and the hi/lo split run on the device
-            ek = self._pk["ext"][k]
-            e = e.to(dev, non_blocking=True).to(torch.float32)
-            pad = torch.zeros((B * L, ek["Epad"]), dtype=torch.float32, device=dev)
-            if dst is None:
-                pad[:, :ek["E"]] = e
-            else:
-                pad[dst, :ek["E"]] = e
-            embs.append(hip.Pair.split(pad, with_lo=self._split))
-        bt.update(B=B, L=L, T=T, N=N, W=W, embs=embs, conv_groups=ch["groups"], char_rows=ch["rows"])
-        if "y_upos" in X:
-            bt["y_upos"] = X["y_upos"].to(dev).to(torch.int32).contiguous()
+            ek = self._pk_cpu["ext"][k]
+            pad = np.zeros((B * L, ek["Epad"]), dtype=np.float32)
+            pad[sb * L + si, :ek["E"]] = e.cpu().numpy().astype(np.float32, copy=False)
+            embs.append(pad)
+        return dict(packed=packed, sizes=sizes, B=B, L=L, T=T, N=N, W=W, embs=embs, conv_groups=ch["groups"],
+                    char_rows=ch["rows"], y_upos=X.get("y_upos"), staging=None)
+
+    def _featurize(self, batch, collate):
+        """list of Sentence -> the host half of a prepared batch (as `_prepare_host`), in one C pass over
+        the objects (csrc/host_collate.c `featurize`: the counterpart of MorphoCollate.collate_fn,
+        utils.py:232-330, fused with the index packing), embeddings written into pinned staging memory.
+        -> None when the C module is missing or the batch is not in the fast format (word.emb not a list of
+        contiguous float32 vectors): the caller then goes through collate_fn + `_prepare_host`."""
+        hm = host.load()
+        if hm is None or not isinstance(collate, MorphoCollate) or not isinstance(batch, list) or not batch:
+            return None
+        B = len(batch)
+        L = max(len(s.words) for s in batch)
+        if L < 1:
+            return None
+        pk = self._pk_cpu
+        l0 = pk.get("char_l0")
+        dims = tuple((ek["E"], ek["Epad"]) for ek in pk["ext"])
+        st = self._staging_acquire([B * L * ep for _, ep in dims], 64 * B * L)
+        n = self._char_layers
+        groups = (hip.ConvGroups * n)()
+        enc = collate._encodings
+        tab = collate.cp_table32()
+        for _ in range(4):
+            try:
+                r = hm.featurize(batch, enc.word2int, collate._wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
+                                 0 if l0 is None else l0["n_case"], L, tuple(b.numpy() for b in st["emb"]), dims,
+                                 ctypes.addressof(groups), self._host_threads, st["ints"].numpy())
+            except TypeError:
+                self._staging_release(st)
+                return None
+            if isinstance(r, tuple):
+                break
+            if isinstance(r, list):
+                tab = collate.cp_table32(r)  # code points seen for the first time: extend the table, run again
+            else:  # the index buffer was too small (very long words): r = the int32 elements it must hold
+                st["ints"] = torch.empty(int(r) + int(r) // 4, dtype=torch.int32, pin_memory=self._device.type == "cuda")
+        else:
+            raise RuntimeError("featurize: the character table does not settle")
+        n_ints, sizes, N, W, rows = r
+        packed = st["ints"].numpy()[:n_ints]
+        embs = [b.numpy()[:B * L * ep].reshape(B * L, ep) for b, (_, ep) in zip(st["emb"], dims)]
+        return dict(packed=packed, sizes=list(sizes), B=B, L=L, T=L + self._root, N=N, W=W, embs=embs,
+                    conv_groups=[groups[l] for l in range(n)], _groups_array=groups, char_rows=list(rows), y_upos=None,
+                    staging=st)
+
+    _host_threads = 4
+    _N_STAGING = 6
+
+    def _staging_acquire(self, emb_sizes, n_ints=0):
+        """A set of pinned host buffers for one batch's external embeddings and packed indices, out of a ring; a set is reused
+        only after the H->D copies that read it have completed (its event)."""
+        import threading
+        ring = self.__dict__.setdefault("_staging", [])
+        lock = self.__dict__.setdefault("_staging_lock", threading.Lock())
+        with lock:
+            st = None
+            for cand in ring:
+                if not cand["busy"]:
+                    st = cand
+                    break
+            if st is None:
+                if len(ring) >= self._N_STAGING:
+                    raise hip.CubeHipError("more than %d featurised batches are waiting for their upload" % self._N_STAGING)
+                st = dict(emb=[], ints=torch.empty(0, dtype=torch.int32), busy=False, event=None)
+                ring.append(st)
+            st["busy"] = True
+        if st["event"] is not None:
+            st["event"].synchronize()
+            st["event"] = None
+        while len(st["emb"]) < len(emb_sizes):
+            st["emb"].append(torch.empty(0, dtype=torch.float32))
+        pin = self._device.type == "cuda"
+        for k, need in enumerate(emb_sizes):
+            if st["emb"][k].numel() < need:
+                st["emb"][k] = torch.empty(need, dtype=torch.float32, pin_memory=pin)
+        if st["ints"].numel() < n_ints:
+            st["ints"] = torch.empty(n_ints, dtype=torch.int32, pin_memory=pin)
+        return st
+
+    @staticmethod
+    def _staging_release(st, event=None):
+        st["event"] = event
+        st["busy"] = False
+
+    @hip.on_device
+    def _upload(self, h):
+        """host half of a prepared batch -> device batch: one int32 upload, one fp32 upload per LM layer
+        (from pinned staging memory when `_featurize` made it), hi/lo split on the device (cube_split_f32)."""
+        self._require_gpu()
+        dev = self._device
+        lib = hip.load()
+        ints = torch.from_numpy(h["packed"]).to(dev, non_blocking=True)
+        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in h["sizes"]])])
+        bt = {n: ints[o:o + s] for n, o, s in zip(self._PART_NAMES, offs[:-1], h["sizes"])}
+        embs = []
+        for e in h["embs"]:
+            src = torch.from_numpy(e).reshape(-1)
+            x = src.to(dev, non_blocking=True)
+            pair = hip.Pair(torch.empty(x.numel(), dtype=torch.bfloat16, device=dev),
+                            torch.empty(x.numel(), dtype=torch.bfloat16, device=dev) if self._split else None)
+            hip.check(lib.cube_split_f32(x.data_ptr(), x.numel(), pair.hi.data_ptr(), hip.ptr(pair.lo), hip.stream_handle()),
+                      "cube_split_f32")
+            embs.append(pair)
+        if h["staging"] is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._staging_release(h["staging"], ev)
+        bt.update(B=h["B"], L=h["L"], T=h["T"], N=h["N"], W=h["W"], embs=embs, conv_groups=h["conv_groups"],
+                  char_rows=h["char_rows"], _keep=h.get("_groups_array"))
+        if h.get("y_upos") is not None:
+            bt["y_upos"] = h["y_upos"].to(dev).to(torch.int32).contiguous()
         return bt
+
+    def _prepare(self, X):
+        """reference-format batch dict (MorphoCollate.collate_fn) -> device index arrays.
+        One packed int32 upload + one fp32 upload per LM layer."""
+        self._require_gpu()
+        return self._upload(self._prepare_host(X))
+
+    def _host_batch(self, batch, collate):
+        """list of Sentence -> host half of the prepared batch: the C featuriser, or the reference-format
+        collate followed by `_prepare_host`."""
+        h = self._featurize(batch, collate)
+        if h is None:
+            X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
+            X.pop("y_upos", None)
+            h = self._prepare_host(X)
+        return h
 
     def _char_layout(self, word_len, W):
         """Ragged layouts of the character CNN.  The masked mean (modules.py:479-483) reads positions
@@ -706,6 +824,12 @@ class Parser(_HipNet):
             raise AssertionError("no single-rooted tree with non-zero probability for sentence(s) %s"
                                  % ids[status != 0].tolist())
         enc = self._encodings
+        hm = host.load()
+        if hm is not None and isinstance(batch, list):
+            # one C call sets the five attributes of every word (csrc/host_collate.c `write_back`)
+            hm.write_back(batch, np.ascontiguousarray(res, dtype=np.int32),
+                          (enc.labels, enc.upos_list, enc.xpos_list, enc.attrs_list))
+            return
         tabs = getattr(self, "_str_tabs", None)
         if tabs is None:  # id -> string tables as object arrays: one fancy-index per batch instead of a list lookup per word
             tabs = self._str_tabs = tuple(np.asarray(t, dtype=object) for t in
@@ -717,20 +841,69 @@ class Parser(_HipNet):
                 w.head, w.label, w.upos, w.xpos, w.attrs = h, l, u, x, a
 
     def _run_batches(self, batches, collate=None):
-        """batches: iterable of (list of Sentence, position label for error messages); two deep in
-        flight; results are written into the Sentence objects."""
+        """batches: iterable of (list of Sentence, position label for error messages).  Per batch the host
+        featurises (one C pass over the objects, the embedding copies on worker threads), uploads, enqueues the kernels,
+        then waits for the oldest batch in flight and writes its results into the Sentence objects;
+        `N_SLOTS` batches are in flight on the device (a batch takes about two step times to pass the three
+        stage streams, so two in flight would leave the first stage idle).
+        `feature_thread` (off by default): featurise one batch ahead on a Python thread — measured slower: the
+        two threads hand the GIL back and forth a hundred times per batch and each hand-over costs a wake-up."""
+        from collections import deque
         collate = collate or self._collate
         self._drain()
-        pending = None
-        for batch, start in batches:
-            X = collate.collate_fn(batch, targets=False) if isinstance(collate, MorphoCollate) else collate.collate_fn(batch)
-            X.pop("y_upos", None)
-            ticket = self.submit(self._prepare(X))
-            if pending is not None:
-                self._write_back(pending[0], pending[1], *self.collect(pending[2]))
-            pending = (batch, start, ticket)
-        if pending is not None:
-            self._write_back(pending[0], pending[1], *self.collect(pending[2]))
+        it = iter(batches)
+
+        def feat(item):
+            batch, start = item
+            if not isinstance(batch, list):
+                batch = list(batch)
+            return batch, start, self._host_batch(batch, collate)
+
+        pending = deque()
+
+        def retire():
+            b0, s0, t0 = pending.popleft()
+            self._write_back(b0, s0, *self.collect(t0))
+
+        if not self.feature_thread:
+            for item in it:
+                batch, start, h = feat(item)
+                pending.append((batch, start, self.submit(self._upload(h))))
+                if len(pending) == self.N_SLOTS:
+                    retire()
+            while pending:
+                retire()
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        pool = self.__dict__.get("_host_pool")
+        if pool is None:
+            pool = self._host_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cube-featurize")
+        ahead = deque()
+        for _ in range(2):
+            item = next(it, None)
+            if item is not None:
+                ahead.append(pool.submit(feat, item))
+        try:
+            while ahead:
+                batch, start, h = ahead.popleft().result()
+                item = next(it, None)
+                if item is not None:
+                    ahead.append(pool.submit(feat, item))
+                pending.append((batch, start, self.submit(self._upload(h))))
+                if len(pending) == self.N_SLOTS:
+                    retire()
+            while pending:
+                retire()
+        finally:
+            for f in ahead:  # an exception above: let the worker finish, give its staging buffers back
+                try:
+                    r = f.result()
+                    if r[2].get("staging") is not None:
+                        self._staging_release(r[2]["staging"])
+                except Exception:
+                    pass
+
+    feature_thread = os.environ.get("CUBE_FEATURE_THREAD", "0") == "1"
 
     @hip.on_device
     def process_bucketed(self, doc, collate, max_tokens=8192):
@@ -749,7 +922,7 @@ class Parser(_HipNet):
         return doc
 
     @hip.on_device
-    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=8192):
+    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=32768):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
         head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
         two deep (featurisation and write-back of neighbours overlap the GPU).

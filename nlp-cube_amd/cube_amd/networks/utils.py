@@ -61,6 +61,24 @@ class MorphoCollate:
             tab[:, cp] = self._char_codes(chr(cp))
         return tab
 
+    def cp_table32(self, missing=None):
+        """int32 [2, top] (char id, case id) by code point, -1 = not seen yet, for the C featuriser
+        (csrc/host_collate.c); `missing` = code points to add (the per-character rule of `_char_codes`)."""
+        tab = getattr(self, "_cp_tab32", None)
+        if tab is None:
+            tab = self._cp_tab32 = np.full((2, 256), -1, dtype=np.int32)
+            missing = list(range(32, 127)) + list(missing or [])
+        if missing:
+            top = max(missing) + 1
+            if top > tab.shape[1]:
+                new = np.full((2, max(top, 2 * tab.shape[1])), -1, dtype=np.int32)
+                new[:, :tab.shape[1]] = tab
+                tab = new
+            for cp in set(missing):
+                tab[:, cp] = self._char_codes(chr(cp))
+            self._cp_tab32 = tab  # a new array object each time it grows: readers keep a consistent one
+        return tab
+
     def collate_fn(self, batch, targets=True):
         """`targets=False` (used by `process`, which drops them anyway) skips the y_* tensors."""
         enc = self._encodings

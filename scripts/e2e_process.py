@@ -1,20 +1,96 @@
-"""End-to-end Parser.process(Document) throughput incl. collate + write-back (secondary metric)."""
-import os, sys, time
+"""End-to-end Parser.process(Document) throughput incl. featurisation, upload and write-back (the secondary
+metric of SURVEY 8d), with the host stages of one batch timed one by one.
+
+    python scripts/e2e_process.py [out.json]
+"""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nlp-cube_amd"))
-import torch
-import bench
-from cube_amd import synth
-from cube_amd.networks.utils import MorphoCollate
-dev = torch.device("cuda:0")
-p, cfg, enc, sd, batches, docs = bench.build_model_and_batches(1, 1, 0, dev, "")
-col = MorphoCollate(enc)
-for bs in (4, 32, 256):
-    n = {4: 512, 32: 2048, 256: 4096}[bs]
-    doc = synth.make_document(enc, [32] * n, seed=77, ext_word_emb=(300,))
-    p.process(doc, col, batch_size=bs)  # warm
-    t0 = time.perf_counter(); p.process(doc, col, batch_size=bs); dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    for s in range(0, n, bs): col.collate_fn(doc.sentences[s:s + bs])
-    tc = time.perf_counter() - t1
-    print("process batch_size=%d: %.0f sentences/s end to end (%d sentences, %.2f s; collate alone %.2f s)" % (bs, n / dt, n, dt, tc))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "nlp-cube_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+from cube_amd import synth  # noqa: E402
+from cube_amd.networks.utils import MorphoCollate  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    p, cfg, enc, sd, batches, docs = bench.build_model_and_batches(1, 1, 0, dev, "")
+    col = MorphoCollate(enc)
+    out = {"rows": []}
+    n = 16384
+    doc = synth.make_document(enc, [32] * 1024, seed=77, ext_word_emb=(300,))
+    # 16k sentences: 16 copies of the words of 1024 (separate objects, separate embedding vectors)
+    import copy
+    big = copy.deepcopy(doc)
+    while len(big.sentences) < n:
+        big.sentences.extend(copy.deepcopy(doc).sentences)
+    for bs, merge in ((256, True), (32, True), (4, True), (4, False)):  # merged device batches: <= 16384 padded tokens
+        m = n if merge else 1024
+        sub = big if merge else doc
+        p.process(sub, col, batch_size=bs, merge=merge)  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p.process(sub, col, batch_size=bs, merge=merge)
+        dt = time.perf_counter() - t0
+        row = dict(batch_size=bs, merge=merge, sentences=m, seconds=dt, sentences_per_s=m / dt)
+        print(json.dumps(row), flush=True)
+        out["rows"].append(row)
+    # host stages of one 256-sentence batch, one by one (single thread, no overlap)
+    batch = big.sentences[:256]
+    reps = 20
+    t = time.perf_counter()
+    for _ in range(reps):
+        h = p._featurize(batch, col)
+        p._staging_release(h["staging"])
+    t_feat = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for _ in range(reps):
+        X = col.collate_fn(batch, targets=False)
+        hs = p._prepare_host(X)
+    t_py = (time.perf_counter() - t) / reps
+    h = p._featurize(batch, col)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        bt = p._upload(dict(h, staging=None))
+    torch.cuda.synchronize()
+    t_up = (time.perf_counter() - t) / reps
+    p._staging_release(h["staging"])
+    t = time.perf_counter()
+    tickets = []
+    for _ in range(reps):
+        tk = p.submit(bt)
+        t_sub_end = time.perf_counter()
+        p.collect(tk)
+    t_sub_col = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for _ in range(reps):
+        tk = p.submit(bt)
+        tickets.append(tk)
+        if len(tickets) == 3:
+            p.collect(tickets.pop(0))
+    t_sub = (time.perf_counter() - t) / reps
+    while tickets:
+        res, status = p.collect(tickets.pop(0))
+    t = time.perf_counter()
+    for _ in range(reps):
+        p._write_back(batch, 0, res, status)
+    t_wb = (time.perf_counter() - t) / reps
+    out["host_stages_ms_per_256_sentences"] = dict(
+        featurize_c=t_feat * 1e3, collate_plus_prepare_python=t_py * 1e3, upload_incl_sync=t_up * 1e3,
+        submit_pipelined=t_sub * 1e3, submit_collect_serial=t_sub_col * 1e3, write_back_c=t_wb * 1e3)
+    print(json.dumps(out["host_stages_ms_per_256_sentences"]), flush=True)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

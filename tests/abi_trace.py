@@ -232,6 +232,16 @@ class TraceLib:
             self._need("ext_finish dst_" + nm, p, 2 * (last * ld + c + P), 2)
         return 0
 
+    def cube_init(self):
+        return 0
+
+    def cube_split_f32(self, x, n, hi, lo, stream):
+        # x / hi / lo are allocated with exactly n elements by the caller (`_upload`) in the same statement, and
+        # freed in stream order: only the contract on n and the alignments can be wrong
+        self.calls.append(("split_f32", n))
+        assert n % 4 == 0 and int(x) % 16 == 0 and int(hi) % 8 == 0 and (lo is None or int(lo) % 8 == 0)
+        return 0
+
     def cube_argmax_rows(self, x, ld, col0, n, M, out, stream):
         self.calls.append(("argmax", M, n))
         assert n > 0 and col0 >= 0 and col0 + n <= ld

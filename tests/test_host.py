@@ -286,3 +286,142 @@ def test_pack_gated_conv_int8_planes():
     # the whole-tensor scale: one unit of (128*HH + X) with activations in units of 1/I8_ONE
     np.testing.assert_allclose(pk["w_scale"].numpy(), (rowmax * 128.0 / hip.I8_ONE ** 2).float().numpy(), rtol=1e-3)
     assert "W8" not in packing.pack_gated_conv(sd, "c", np.arange(32), int8=True)  # Kc = 32
+
+
+def _host_dicts(p, col, sents):
+    """(C featuriser, collate_fn + _prepare_host) for one batch."""
+    fast = p._featurize(list(sents), col)
+    assert fast is not None, "the C featuriser refused a batch in the fast format"
+    X = col.collate_fn(list(sents), targets=False)
+    return fast, p._prepare_host(X)
+
+
+def _assert_same_host_batch(fast, slow):
+    for k in ("B", "L", "T", "N", "W"):
+        assert fast[k] == slow[k], k
+    assert list(fast["sizes"]) == list(slow["sizes"])
+    assert list(fast["char_rows"]) == list(slow["char_rows"])
+    np.testing.assert_array_equal(fast["packed"], slow["packed"])
+    assert fast["packed"].dtype == np.int32
+    assert len(fast["embs"]) == len(slow["embs"])
+    for a, b in zip(fast["embs"], slow["embs"]):
+        np.testing.assert_array_equal(a, b)
+    assert len(fast["conv_groups"]) == len(slow["conv_groups"])
+    for ga, gb in zip(fast["conv_groups"], slow["conv_groups"]):
+        assert ga.n == gb.n
+        for f in ("row0_in", "n_rows", "seq_in", "row0_out", "seq_out", "word0"):
+            assert list(getattr(ga, f))[:ga.n] == list(getattr(gb, f))[:gb.n], f
+
+
+@pytest.mark.parametrize("which", ["parser", "tagger"])
+def test_c_featurizer_equals_collate_plus_prepare(which):
+    """csrc/host_collate.c `featurize` (one pass over the Sentence objects) gives bit-identical arrays to
+    MorphoCollate.collate_fn (pinned to the reference by G1, utils.py:232-330) followed by the host half of
+    `_prepare`: packed indices, ragged character-CNN groups, padded embedding rows.  Ragged sentences, words
+    longer than the 31 length groups, upper / symbol / non-ASCII / astral characters, unknown words, K = 2
+    embedding layers, and twice in a row (the staging buffers are reused)."""
+    from cube_amd.networks.parser import Parser
+    from cube_amd.networks.tagger import Tagger
+    if which == "parser":
+        case = cases.TINY
+        cfg, enc, sd = cases.parser_model(case)
+        p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    else:
+        case = cases.TINY_TAGGER
+        cfg, enc, sd = cases.tagger_model(case)
+        p = Tagger(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    doc = cases.document(case, enc, "g6")
+    w = doc.sentences[3].words
+    w[0].word = "Ünïcode"
+    w[-1].word = "x" * 45            # beyond the last length group
+    doc.sentences[5].words[0].word = "\U0001F600ok中"   # astral + CJK: unknown characters
+    doc.sentences[7].words[0].word = "ǅ"   # title-case letter: lower != upper != itself
+    for sents in (doc.sentences, doc.sentences[:4], doc.sentences[3:4], doc.sentences[10:27]):
+        fast, slow = _host_dicts(p, col, sents)
+        _assert_same_host_batch(fast, slow)
+        p._staging_release(fast["staging"])
+    # not the fast format (float64 vectors): the caller must fall back
+    doc.sentences[0].words[0].emb = [e.astype(np.float64) for e in doc.sentences[0].words[0].emb]
+    assert p._featurize(list(doc.sentences[:2]), col) is None
+    h = p._host_batch(list(doc.sentences[:2]), col)
+    assert h["B"] == 2
+
+
+def test_c_featurizer_full_config_and_generic_objects():
+    """Default ParserConfig (first character layer as table look-ups: combined char x case ids) and plain
+    objects without __slots__ (what the reference's own Word / Sentence classes are)."""
+    from cube_amd.networks.parser import Parser
+    cfg, enc, sd = cases.parser_model(cases.FULL)
+    p = Parser(cfg, enc, ext_word_emb=[300])
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    doc = synth.make_document(enc, [32] * 24 + [5, 1, 17], seed=77, ext_word_emb=(300,))
+    fast, slow = _host_dicts(p, col, doc.sentences)
+    _assert_same_host_batch(fast, slow)
+    p._staging_release(fast["staging"])
+
+    class W:   # no __slots__
+        pass
+
+    class S:
+        pass
+    plain = []
+    for s in doc.sentences[:5]:
+        t = S()
+        t.lang_id, t.words = s.lang_id, []
+        for w in s.words:
+            v = W()
+            v.word, v.emb = w.word, w.emb
+            t.words.append(v)
+        plain.append(t)
+    fast2 = p._featurize(plain, col)
+    slow2 = p._prepare_host(col.collate_fn(doc.sentences[:5], targets=False))
+    _assert_same_host_batch(fast2, slow2)
+    p._staging_release(fast2["staging"])
+
+
+def test_c_write_back_equals_python_loop():
+    from cube_amd import host
+    from cube_amd.networks.parser import Parser
+    hm = host.load()
+    assert hm is not None
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    a, b = cases.document(case, enc, "g6"), cases.document(case, enc, "g6")
+    B, L = len(a.sentences), max(len(s.words) for s in a.sentences)
+    rng = np.random.default_rng(0)
+    res = np.stack([rng.integers(0, L + 1, (B, L)), rng.integers(0, len(enc.labels), (B, L)),
+                    rng.integers(0, len(enc.upos_list), (B, L)), rng.integers(0, len(enc.xpos_list), (B, L)),
+                    rng.integers(0, len(enc.attrs_list), (B, L))]).astype(np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    p._write_back(a.sentences, 0, res, status)                      # the C call
+    p._write_back(tuple(b.sentences), 0, res, status)                # not a list: the Python loop
+    assert str(a) == str(b)
+    assert isinstance(a.sentences[0].words[0].head, int)
+    bad = res.copy()
+    bad[2, 0, 0] = len(enc.upos_list)
+    with pytest.raises(IndexError):
+        hm.write_back(a.sentences, bad, (enc.labels, enc.upos_list, enc.xpos_list, enc.attrs_list))
+    with pytest.raises(AssertionError):
+        p._write_back(a.sentences, 0, res, np.array([0, 1] + [0] * (B - 2), dtype=np.int32))
+
+
+def test_batch_geometry_keys_c_equals_python(monkeypatch):
+    """sharding.sentence_batch_keys through the C pass (`geometry`) and through the Python loops."""
+    from cube_amd import host, sharding
+    _, enc, _ = cases.parser_model(cases.TINY)
+    rng = np.random.default_rng(4)
+    doc = synth.make_document(enc, rng.integers(1, 9, size=203), seed=5, ext_word_emb=(4,), max_word_len=6)
+
+    def cap(k):
+        return min(1024, 256 // (k[0] + 1))
+    for bs in (4, 7, 32):
+        starts = list(range(0, len(doc.sentences), bs))
+        fast = sharding.sentence_batch_keys(doc.sentences, starts, bs, cap)
+        monkeypatch.setattr(host, "load", lambda: None)
+        slow = sharding.sentence_batch_keys(doc.sentences, starts, bs, cap)
+        monkeypatch.undo()
+        assert fast == slow, bs
