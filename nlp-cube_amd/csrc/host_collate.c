@@ -664,6 +664,69 @@ done:
   return result;
 }
 
+/* write_back_flat(sentences, ids, tables): ids C-contiguous int32 [n_words, 5] = (head, label, upos, xpos, attrs)
+ * of every word of `sentences` in order (the layout in which a shard's results travel between ranks,
+ * cube_amd/sharding.py); tables as for write_back. */
+static PyObject* write_back_flat(PyObject* self, PyObject* args) {
+  PyObject *sents, *tabs;
+  PyArrayObject* ids;
+  if (!PyArg_ParseTuple(args, "O!O!O!", &PyList_Type, &sents, &PyArray_Type, &ids, &PyTuple_Type, &tabs)) return NULL;
+  if (PyArray_TYPE(ids) != NPY_INT32 || PyArray_NDIM(ids) != 2 || PyArray_DIM(ids, 1) != 5 || !PyArray_IS_C_CONTIGUOUS(ids) ||
+      PyTuple_GET_SIZE(tabs) != 4) {
+    PyErr_SetString(PyExc_ValueError, "write_back_flat: ids must be C-contiguous int32 [n_words, 5], tables a 4-tuple");
+    return NULL;
+  }
+  PyObject* tab[4];
+  Py_ssize_t ntab[4];
+  for (int t = 0; t < 4; ++t) {
+    tab[t] = PyTuple_GET_ITEM(tabs, t);
+    if (!PyList_Check(tab[t])) {
+      PyErr_SetString(PyExc_ValueError, "write_back_flat: the id -> string tables must be lists");
+      return NULL;
+    }
+    ntab[t] = PyList_GET_SIZE(tab[t]);
+  }
+  static const int field_of[4] = {F_LABEL, F_UPOS, F_XPOS, F_ATTRS};
+  const int32_t* R = (const int32_t*)PyArray_DATA(ids);
+  const Py_ssize_t total = PyArray_DIM(ids, 0);
+  Py_ssize_t k = 0;
+  WordLayout wl;
+  wl.tp = NULL;
+  const Py_ssize_t B = PyList_GET_SIZE(sents);
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws) return NULL;
+    if (!PyList_Check(ws) || k + PyList_GET_SIZE(ws) > total) {
+      Py_DECREF(ws);
+      PyErr_Format(PyExc_ValueError, "write_back_flat: the sentences hold more words than the %zd result rows", total);
+      return NULL;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(ws);
+    for (Py_ssize_t j = 0; j < n; ++j, ++k) {
+      PyObject* w = PyList_GET_ITEM(ws, j);
+      if (j + 8 < n) { __builtin_prefetch(PyList_GET_ITEM(ws, j + 8), 1); __builtin_prefetch((char*)PyList_GET_ITEM(ws, j + 8) + 64, 1); }
+      PyObject* h = PyLong_FromLong((long)R[k * 5]);
+      if (!h || word_set(w, &wl, F_HEAD, h) != 0) { Py_XDECREF(h); Py_DECREF(ws); return NULL; }
+      Py_DECREF(h);
+      for (int t = 0; t < 4; ++t) {
+        const int32_t id = R[k * 5 + 1 + t];
+        if (id < 0 || id >= ntab[t]) {
+          Py_DECREF(ws);
+          PyErr_Format(PyExc_IndexError, "write_back_flat: id %d outside table %d", (int)id, t);
+          return NULL;
+        }
+        if (word_set(w, &wl, field_of[t], PyList_GET_ITEM(tab[t], id)) != 0) { Py_DECREF(ws); return NULL; }
+      }
+    }
+    Py_DECREF(ws);
+  }
+  if (k != total) {
+    PyErr_Format(PyExc_ValueError, "write_back_flat: %zd result rows for %zd words", total, k);
+    return NULL;
+  }
+  Py_RETURN_NONE;
+}
+
 /* timing() -> (calls, seconds in: sizes pass, object pass, index arrays, embedding copies) since the last call */
 static PyObject* timing(PyObject* self, PyObject* args) {
   PyObject* r = Py_BuildValue("(ldddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3]);
@@ -779,6 +842,7 @@ static PyMethodDef methods[] = {
     {"stack_rows", stack_rows, METH_VARARGS, "copy N equal-size contiguous buffers into one [N, size] buffer"},
     {"fill_ragged", fill_ragged, METH_VARARGS, "ragged int64 values -> zero-padded int64 [N, width] rows"},
     {"featurize", featurize, METH_VARARGS, "Sentence objects -> packed index arrays + padded embedding rows of one batch"},
+    {"write_back_flat", write_back_flat, METH_VARARGS, "result ids [n_words, 5] -> the words, in order"},
     {"timing", timing, METH_NOARGS, "accumulated seconds per stage of featurize since the last call"},
     {"geometry", geometry, METH_VARARGS, "words per sentence and longest word per sentence"},
     {"write_back", write_back, METH_VARARGS, "result ids -> head / label / upos / xpos / attrs of every word"},

@@ -840,7 +840,9 @@ class Parser(_HipNet):
             for w, h, l, u, x, a in zip(s.words, heads[b], lab[b], up[b], xp[b], at[b]):
                 w.head, w.label, w.upos, w.xpos, w.attrs = h, l, u, x, a
 
-    def _run_batches(self, batches, collate=None):
+    reports_results = True  # process / process_bucketed take on_result(batch, where, res[5, B, L])
+
+    def _run_batches(self, batches, collate=None, on_result=None):
         """batches: iterable of (list of Sentence, position label for error messages).  Per batch the host
         featurises (one C pass over the objects, the embedding copies on worker threads), uploads, enqueues the kernels,
         then waits for the oldest batch in flight and writes its results into the Sentence objects;
@@ -863,7 +865,10 @@ class Parser(_HipNet):
 
         def retire():
             b0, s0, t0 = pending.popleft()
-            self._write_back(b0, s0, *self.collect(t0))
+            res, status = self.collect(t0)
+            self._write_back(b0, s0, res, status)
+            if on_result is not None:
+                on_result(b0, s0, res)
 
         if not self.feature_thread:
             for item in it:
@@ -906,7 +911,7 @@ class Parser(_HipNet):
     feature_thread = os.environ.get("CUBE_FEATURE_THREAD", "0") == "1"
 
     @hip.on_device
-    def process_bucketed(self, doc, collate, max_tokens=8192):
+    def process_bucketed(self, doc, collate, max_tokens=8192, on_result=None):
         """Throughput mode for ragged documents: sentences sorted by length and
         packed into batches of at most `max_tokens` padded positions, results written back in place.
         NOT the reference's batch composition: scores differ from `process` in the way the
@@ -918,11 +923,11 @@ class Parser(_HipNet):
         self._collate = collate
         sents = doc.sentences
         groups = bucketed_batches([len(s.words) for s in sents], max_tokens)
-        self._run_batches(([sents[i] for i in idx], int(idx[0])) for idx in groups)
+        self._run_batches((([sents[i] for i in idx], np.asarray(idx)) for idx in groups), on_result=on_result)
         return doc
 
     @hip.on_device
-    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=32768):
+    def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=32768, on_result=None):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
         head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
         two deep (featurisation and write-back of neighbours overlap the GPU).
@@ -936,7 +941,7 @@ class Parser(_HipNet):
         sents = doc.sentences
         starts = list(range(0, len(sents), batch_size))
         if not merge or len(starts) < 2:
-            self._run_batches((sents[start:start + batch_size], start) for start in starts)
+            self._run_batches(((sents[start:start + batch_size], start) for start in starts), on_result=on_result)
             return doc
         from cube_amd.sharding import merged_reference_batches, sentence_batch_keys
 
@@ -948,5 +953,5 @@ class Parser(_HipNet):
             for g in groups:
                 ids = [i for r in g for i in range(starts[r], min(starts[r] + batch_size, len(sents)))]
                 yield [sents[i] for i in ids], np.asarray(ids)
-        self._run_batches(batches())
+        self._run_batches(batches(), on_result=on_result)
         return doc
