@@ -18,7 +18,7 @@
  *   cube_split_f32          the fp32 -> operand-plane cast of the external embeddings (parser.py:130-136)
  *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197; tagger.py:118-119)
  *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
- *   cube_bilstm_recurrent   torch.lstm recurrence, 1 layer, both directions (parser.py:201)
+ *   cube_bilstm_recurrent[_i8]  torch.lstm recurrence, 1 layer, both directions (parser.py:201)
  *   cube_biaffine_arc       PairwiseBilinear bmm + torch.softmax (modules.py:518-533;
  *                           parser.py:214-216,425)
  *   cube_mst_decode         ChuLiuEdmondsDecoder.decode (cube/networks/utils.py:565-577,
@@ -190,6 +190,21 @@ int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* ou
  * out bf16 [B*T, ld_out]: h_fwd -> cols [col0, col0+H), h_bwd -> [col0+H, col0+2H).        */
 int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, int B, int T, int H,
                           void* out, void* out_lo, int ld_out, int col0, void* stream);
+
+/* The same recurrence (torch.lstm, parser.py:71-72,201) with the hidden-state weights RESIDENT in VGPRs and LDS and
+ * the product h_{t-1} . W_hh^T in two-slice fixed point on the int8 matrix cores: h = (128*hi + lo) / CUBE_I8_ONE
+ * (|h| < 1), a weight row n in 12 bits with its own scale, w[n, k] = (16*hi + lo) * wmax[n] / 2032, hi*hi, hi*lo and
+ * lo*hi accumulated exactly in int32 (lo*lo dropped); gates, cell state and the input projections stay fp32.
+ * gx, out, out_lo, ld_out, col0 as for cube_bilstm_recurrent (out_lo may be NULL).  KP = H rounded up to 32,
+ * n64 = KP / 64, tail = KP % 64 != 0:
+ *   whi   int8 [2][U][4][n64*1024 + tail*512]: fragments [lane][16] of hi[row u*64 + g*16 + (lane & 15)]
+ *         [ks*64 + (lane >> 4)*16 + j], then the tail [lane][8] at k = n64*64 + (lane >> 4)*8 + j
+ *   wlo4  uint8 [2][U][4][n64*512 + tail*256]: the nibbles lo + 8 of the same fragments, two to a byte: 32-bit word m
+ *         of a lane, byte b = nib[k0 + 8m + b] | nib[k0 + 8m + 4 + b] << 4
+ *   wscale f32 [2][U*64]: 16 * wmax[n] / (CUBE_I8_ONE * 2032) in packed gate-row order.
+ * Both tensors gx and out must be smaller than 2 GiB (32-bit lane offsets).                                */
+int cube_bilstm_recurrent_i8(const float* gx, const void* whi, const void* wlo4, const float* wscale, int B, int T, int H,
+                             void* out, void* out_lo, int ld_out, int col0, void* stream);
 
 /* Arc scores + row softmax.  u bf16 [B*T, ld_u] (= [h1;1] W), h2 bf16 [B*T, ld_h2] (cols
  * col_h2..col_h2+D), D % 32 == 0.  logits/probs f32 [B, T-1, T]: [b,i,j] = u[b,i+1,:].h2[b,j,:],

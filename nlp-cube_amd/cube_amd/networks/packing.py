@@ -276,6 +276,55 @@ def lstm_gate_rows(H):
     return rows
 
 
+LSTM8_WONE = 2032  # 127 * 16: 12-bit recurrent weights, w = (16*hi + lo) * wmax / LSTM8_WONE (csrc/lstm_i8.hip)
+
+
+def pack_lstm_i8(whh_dirs, H):
+    """Recurrent weights of one BiLSTM layer for cube_bilstm_recurrent_i8 (include/cube_hip.h).
+    whh_dirs: two f32 [G, >= H] matrices in packed gate-row order (`lstm_gate_rows`; padding rows zero).
+    Row n: q = round(w / max|w[n]| * 2032) = 16*hi + lo, hi in [-127, 127] (int8), lo in [-8, 7] stored as the
+    nibble lo + 8.  K is padded to a multiple of 32: n64 = KP // 64 fragments of K = 64, then one of K = 32.
+    -> dict(hi uint8 [2, U, 4, WHI_TILE], lo4 uint8 [2, U, 4, WLO_TILE], scale f32 [2, G]) in MFMA-fragment order:
+       hi fragment ks: [lane][16 bytes], byte j of lane (l15, lq) = hi[row u*64 + g*16 + l15][ks*64 + lq*16 + j];
+       tail: [lane][8], k = n64*64 + lq*8 + j;  lo4 fragment: [lane][8 bytes] = two words, word m byte b =
+       nib[k0 + 4*(2m) + b] | nib[k0 + 4*(2m+1) + b] << 4 with k0 = ks*64 + lq*16; tail: [lane][4], one word."""
+    from cube_amd.hip import I8_ONE
+    G = whh_dirs[0].shape[0]
+    U = G // 64
+    KP = 32 * ((U + 1) // 2)
+    n64, tail = KP // 64, (KP % 64) != 0
+    his, los, scales = [], [], []
+    for w in whh_dirs:
+        wp = torch.zeros((G, KP), dtype=torch.float64)
+        wp[:, :H] = w[:, :H].double()
+        wmax = wp.abs().amax(dim=1).clamp(min=1e-30)
+        q = torch.round(wp / wmax[:, None] * LSTM8_WONE).to(torch.int32)
+        hi = (q + 8) >> 4
+        lo = q - (hi << 4)
+        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -8 and int(lo.max()) <= 7
+        nib = (lo + 8).to(torch.uint8)
+        hi8 = hi.to(torch.int8).view(torch.uint8)
+        r = hi8.view(U, 4, 16, KP)                                   # [u][g][l15][k]
+        nb = nib.view(U, 4, 16, KP)
+        hp, lp = [], []
+        for ks in range(n64):
+            f = r[:, :, :, ks * 64:(ks + 1) * 64].reshape(U, 4, 16, 4, 16)          # [u][g][l15][lq][j]
+            hp.append(f.permute(0, 1, 3, 2, 4).reshape(U, 4, 1024))                  # lane = lq*16 + l15
+            n_ = nb[:, :, :, ks * 64:(ks + 1) * 64].reshape(U, 4, 16, 4, 4, 4)       # [u][g][l15][lq][reg m][byte b]
+            pk = (n_[..., 0::2, :] | (n_[..., 1::2, :] << 4))                        # [u][g][l15][lq][2][4]
+            lp.append(pk.permute(0, 1, 3, 2, 4, 5).reshape(U, 4, 512))
+        if tail:
+            f = r[:, :, :, n64 * 64:n64 * 64 + 32].reshape(U, 4, 16, 4, 8)
+            hp.append(f.permute(0, 1, 3, 2, 4).reshape(U, 4, 512))
+            n_ = nb[:, :, :, n64 * 64:n64 * 64 + 32].reshape(U, 4, 16, 4, 2, 4)     # [..][lq][reg m][byte b]
+            pk = (n_[..., 0, :] | (n_[..., 1, :] << 4))                              # [u][g][l15][lq][4]
+            lp.append(pk.permute(0, 1, 3, 2, 4).reshape(U, 4, 256))
+        his.append(torch.cat(hp, dim=2))
+        los.append(torch.cat(lp, dim=2))
+        scales.append((16.0 * wmax / (I8_ONE * LSTM8_WONE)).float())
+    return dict(hi=torch.stack(his).contiguous(), lo4=torch.stack(los).contiguous(), scale=torch.stack(scales).contiguous())
+
+
 def pack_parser(sd, cfg, enc_sizes, ext_dims):
     """-> (dict of packed CPU tensors / ints, Layout)."""
     lay = Layout(cfg, len(ext_dims))
@@ -315,7 +364,7 @@ def pack_parser(sd, cfg, enc_sizes, ext_dims):
         U, KS = G // 64, KH // 32
         w4 = torch.stack(hh, 0).view(2, U, 4, 16, KS, 4, 8)       # [d][u][g][l15][ks][lq][j]
         frag = w4.permute(0, 1, 2, 4, 5, 3, 6).reshape(2, U, 4, KS, 64, 8)  # lane = lq*16 + l15
-        pk["lstm"].append(dict(ih=ih, whh=_bf16(frag.contiguous()), G=G))
+        pk["lstm"].append(dict(ih=ih, whh=_bf16(frag.contiguous()), G=G, whh8=pack_lstm_i8(hh, H)))
     # _pre_out reads [h_fwd | h_bwd | lang]  (reference order)
     pk["pre_out"] = pack_linear(sd["_pre_out.linear_layer.weight"], sd["_pre_out.linear_layer.bias"])
     pp_w = pk["pre_out"]["N"]  # width of the pre_parsing buffer (pad columns are tanh(0) = 0)

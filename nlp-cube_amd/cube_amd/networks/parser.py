@@ -91,6 +91,9 @@ class _HipNet:
         # character-CNN layers >= 1 in int8x2 fixed point (cube_gemm_i8x2; bf16x3 mode only): their inputs
         # are gate outputs, |x| < 1.  False = bf16x3 there too; CUBE_CHAR_I8=0 does the same.
         self.char_int8 = os.environ.get("CUBE_CHAR_I8", "1") != "0"
+        # BiLSTM recurrence with the hidden-state weights resident in VGPRs + LDS and h . W_hh in two-slice int8 fixed
+        # point (cube_bilstm_recurrent_i8; bf16x3 mode only).  False / CUBE_LSTM_I8=0: bf16x3, W_hh streamed from L2.
+        self.lstm_int8 = os.environ.get("CUBE_LSTM_I8", "1") != "0"
         self._timing = None
         self._streams = None
         self._layouts = {}
@@ -616,8 +619,15 @@ class Parser(_HipNet):
             dst = xla if l % 2 == 0 else xlb
             hip.gemm(src, src_ld, BT, ih["K"], ih["W"], ih["N"], ih["bias"], hip.EPI_F32, out0=gx, ldo0=G2, n_valid=G2,
                      stream=st)
-            hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].hi.data_ptr(), lo(ly["whh"].lo), B, T, H,
-                                                dst.hi.data_ptr(), lo(dst.lo), xl_w, 0, st), "cube_bilstm_recurrent")
+            if self.lstm_int8 and self._split:
+                # hidden-state weights resident in VGPRs + LDS, recurrent product in two-slice int8 fixed point
+                w8 = ly["whh8"]
+                hip.check(lib.cube_bilstm_recurrent_i8(gx.data_ptr(), w8["hi"].data_ptr(), w8["lo4"].data_ptr(),
+                                                       w8["scale"].data_ptr(), B, T, H, dst.hi.data_ptr(), lo(dst.lo), xl_w, 0,
+                                                       st), "cube_bilstm_recurrent_i8")
+            else:
+                hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].hi.data_ptr(), lo(ly["whh"].lo), B, T, H,
+                                                    dst.hi.data_ptr(), lo(dst.lo), xl_w, 0, st), "cube_bilstm_recurrent")
             src, src_ld = dst, xl_w
         # ---- pre_parsing (parser.py:202-203) and the arc scorer (modules.py:518-533, 550-579)
         q = pk["pre_out"]

@@ -155,3 +155,102 @@ def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixt
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
     print("char_int8=%s %s: arc %.2e upos %.2e label %.2e" % (i8, doc_key, _rel(arc, ref_arc),
           _rel(r["upos_logits"].cpu().numpy(), g["%s/upos" % doc_key]), _rel(lab[same], ref_lab[same])))
+
+
+# ------------------------------------------------------------------------------------------
+# cube_bilstm_recurrent_i8: hidden-state weights resident in VGPRs + LDS, 15-bit h x 12-bit W_hh on the int8 MFMAs
+# ------------------------------------------------------------------------------------------
+def _lstm_i8_reference(gx, whh_dirs, H, B, T):
+    """The kernel's arithmetic in NumPy: exact integer products of the quantised operands, fp64 gate math."""
+    from cube_amd.hip import I8_ONE
+    from cube_amd.networks.packing import LSTM8_WONE
+    G = whh_dirs[0].shape[0]
+    U = G // 64
+    out = np.zeros((B, T, 2 * H))
+    cols = np.array([[u * 64 + g * 16 + j for u in range(U) for j in range(16)] for g in range(4)])   # [gate][hidden]
+    for d, w in enumerate(whh_dirs):
+        w = w.double().numpy()
+        wmax = np.maximum(np.abs(w).max(axis=1), 1e-30)
+        q = np.round(w / wmax[:, None] * LSTM8_WONE)
+        whi = np.floor((q + 8) / 16)
+        wlo = q - 16 * whi
+        scale = 16.0 * wmax / (I8_ONE * LSTM8_WONE)
+        h = np.zeros((B, U * 16))
+        c = np.zeros((B, U * 16))
+        for s in range(T):
+            t = T - 1 - s if d else s
+            hq = np.clip(np.round(h * I8_ONE), -I8_ONE, I8_ONE)
+            hhi = np.floor((hq + 64) / 128)
+            hlo = hq - 128 * hhi
+            K = w.shape[1]
+            acc = 128.0 * (hhi[:, :K] @ whi.T) + 8.0 * (hhi[:, :K] @ wlo.T) + (hlo[:, :K] @ whi.T)
+            pre = acc * scale[None, :] + gx[:, t, d * G:(d + 1) * G]
+            i, f, g, o = (pre[:, cols[k]] for k in range(4))
+            sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+            c = sig(f) * c + sig(i) * np.tanh(g)
+            h = sig(o) * np.tanh(c)
+            out[:, t, d * H:(d + 1) * H] = h[:, :H]
+    return out
+
+
+@pytest.mark.parametrize("H,B,T", [(200, 37, 33), (16, 5, 7), (64, 16, 12), (96, 3, 129), (40, 50, 4), (256, 9, 5)])
+def test_bilstm_i8_matches_its_fixed_point_contract(dev, H, B, T):
+    """The resident-weight recurrence against a NumPy restatement of the same fixed-point arithmetic (exact integer
+    products, fp64 gates): every shape class of the kernel — K = 64 steps with and without the K = 32 tail, one wave to
+    sixteen, a batch that does not fill the last 16-sentence workgroup, input projections through LDS (H <= 208) and
+    through registers.  A wrong MFMA operand map or nibble order cannot pass: the weights are asymmetric random."""
+    from cube_amd import hip
+    from cube_amd.networks import packing
+    lib = hip.load()
+    rng = np.random.default_rng(H * 1000 + B)
+    rows1 = packing.lstm_gate_rows(H)
+    G = len(rows1)
+    v = np.where(rows1 >= 0)[0]
+    whh = []
+    for d in range(2):
+        w = torch.from_numpy(rng.uniform(-1, 1, size=(4 * H, H)) / np.sqrt(H)).float()
+        wp = torch.zeros((G, H), dtype=torch.float32)
+        wp[torch.from_numpy(v)] = w[torch.from_numpy(rows1[v])]
+        whh.append(wp)
+    pk = packing.pack_lstm_i8(whh, H)
+    gx = np.zeros((B, T, 2 * G), dtype=np.float32)
+    gx[:, :, np.concatenate([v, G + v])] = rng.standard_normal((B, T, 2 * len(v))).astype(np.float32)
+    ld_out, col0 = 2 * H + 24, 8
+    out = torch.zeros((B * T, ld_out), dtype=torch.bfloat16, device=dev)
+    out_lo = torch.zeros_like(out)
+    d_gx = torch.from_numpy(gx).to(dev)
+    d_hi, d_lo, d_sc = pk["hi"].to(dev), pk["lo4"].to(dev), pk["scale"].to(dev)
+    hip.check(lib.cube_bilstm_recurrent_i8(d_gx.data_ptr(), d_hi.data_ptr(), d_lo.data_ptr(), d_sc.data_ptr(), B, T, H,
+                                           out.data_ptr(), out_lo.data_ptr(), ld_out, col0, hip.stream_handle()),
+              "cube_bilstm_recurrent_i8")
+    torch.cuda.synchronize()
+    got = (out.float() + out_lo.float()).cpu().numpy().reshape(B, T, ld_out)
+    assert (got[:, :, :col0] == 0).all() and (got[:, :, col0 + 2 * H:] == 0).all()
+    exp = _lstm_i8_reference(gx.astype(np.float64), whh, H, B, T)
+    err = np.abs(got[:, :, col0:col0 + 2 * H] - exp).max()
+    assert err < 3e-4, err   # one step of the 15-bit h grid is 6e-5; a flipped rounding propagates below that
+
+
+def test_parser_lstm_int8_and_bf16x3_both_match_reference(dev, golden_dir):
+    """rnn_out is not an output of the path, but the arc and label scores read nothing else: with the BiLSTM in int8x2
+    (default) and in bf16x3 (`lstm_int8 = False`) they stay within 1e-3 of the REFERENCE's own (G3) and of each other."""
+    from tests.test_gpu_parity import _model, _rel
+    from cube_amd.networks.utils import MorphoCollate
+    g = np.load(os.path.join(golden_dir, "g3_forward_full.npz"))
+    p, cfg, enc, sd = _model(dev, cases.FULL, "bf16x3")
+    res = {}
+    try:
+        for flag in (True, False):
+            p.lstm_int8 = flag
+            for key in ("full_8x32", "full_2x128"):
+                doc = cases.document(cases.FULL, enc, key)
+                X = MorphoCollate(enc).collate_fn(doc.sentences, targets=False)
+                r = p.decode_batch(X)
+                torch.cuda.synchronize()
+                arc = r["arc_logits"].cpu().numpy().copy()
+                assert _rel(arc, g["%s/arc_logits" % key]) < 1e-3, (flag, key, _rel(arc, g["%s/arc_logits" % key]))
+                res[(flag, key)] = arc
+    finally:
+        p.lstm_int8 = True
+    for key in ("full_8x32", "full_2x128"):
+        assert _rel(res[(True, key)], res[(False, key)]) < 2e-4

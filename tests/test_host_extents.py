@@ -34,7 +34,7 @@ def test_decode_batch_extents(monkeypatch, case, keys, precision):
         r = p.decode_batch_prepared(bt)
         names = [c[0] for c in lib.calls[n0:]]
         assert names.count("mst") == 1 and names.count("label") == 1 and names.count("biaffine") == 1
-        assert names.count("bilstm") == cfg.rnn_layers
+        assert names.count("bilstm") + names.count("bilstm_i8") == cfg.rnn_layers
         B, L = bt["B"], bt["L"]
         assert tuple(r["packed"].shape) == (5, B, L) and tuple(r["arc_logits"].shape) == (B, L, L + 1)
         assert tuple(r["upos"].shape) == (B, L) and tuple(r["status"].shape) == (B,)
