@@ -202,24 +202,24 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
     }
 #endif
     // ---- gates (the input projections of this step have landed in LDS by now)
-    if constexpr (GXL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GXL) {
+      // all sixteen values out of LDS first, then the request for the NEXT step goes out before the gate math instead
+      // of after it: the projections come from HBM and need every bit of lead they can get
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gxv[g][r] = *reinterpret_cast<const float*>(gx_mine + (g * 4 + r) * 256 + lane * 4);
+#ifndef EXP_NOGX
+      if (s + 1 < T) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are done before the DMA rewrites the area
+        fetch_gx(dir ? t - 1 : t + 1);
+      }
+#endif
+    }
     unsigned char* hn = s_h + (cur ^ 1) * 2 * HIMG;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if constexpr (GXL) {  // two rows' worth of LDS reads at a time: all sixteen at once cost more registers than are left
-        if ((r & 1) == 0) {
-          SCHED_FENCE();
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            gxv[g][r] = *reinterpret_cast<const float*>(gx_mine + (g * 4 + r) * 256 + lane * 4);
-            gxv[g][r + 1] = *reinterpret_cast<const float*>(gx_mine + (g * 4 + r + 1) * 256 + lane * 4);
-          }
-        }
-      }
-      // sigmoid(a) * tanh(b) = (1 - e^-2b) / ((1 + e^-a)(1 + e^-2b)): two exponentials and ONE reciprocal instead of two
-      // of each (the transcendentals of the gate phase cost as much as the MFMAs of the step: both run per SIMD, and
-      // the step barrier keeps them from overlapping).  b is clamped so that e^-2b stays finite; e^-a may overflow,
-      // the quotient then is the correct limit 0.
       const float pi = (float)acc[0][r] * sc[0] + gxv[0][r];
       const float pf = (float)acc[1][r] * sc[1] + gxv[1][r];
       const float pg = fminf(fmaxf((float)acc[2][r] * sc[2] + gxv[2][r], -15.f), 15.f);
@@ -250,10 +250,8 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
       }
     }
 #ifndef EXP_NOGX
-    if (s + 1 < T) {
-      if constexpr (GXL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are done before the DMA rewrites
-      fetch_gx(dir ? t - 1 : t + 1);
-    }
+    if constexpr (!GXL)
+      if (s + 1 < T) fetch_gx(dir ? t - 1 : t + 1);
 #endif
     __syncthreads();
     cur ^= 1;
