@@ -26,6 +26,21 @@
 
 namespace {
 
+// A task is ONE wavefront, and a workgroup holds several independent tasks (below): all synchronisation is
+// wave-level.  The workgroup-scope fence makes the wave's LDS and global writes (the score matrix lives in the
+// workspace for long sentences) visible to its own later reads; no s_barrier, which would tie tasks of different
+// lengths together.
+#define MST_SYNC()                                            \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+// Tasks (waves) per workgroup.  The decode runs beside the 160-KiB-LDS GEMM tiles of the next batches: with one task
+// per workgroup the 256 first-pass workgroups land on 256 different CUs, 11 KB of LDS each, and no CU can take a GEMM
+// tile until they are done.  Packed, the same tasks sit on B / 14 CUs (L = 32) and leave the rest of the chip alone.
+constexpr int MST_MAX_WAVES = 16;
+constexpr int MST_ROOT_MAX_BLOCKS = 96;  // CUs the rooted re-runs may spread over when tasks are packed
+
 constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
 constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences (node ids are bytes): S lives in the workspace (HBM/L2), slow but exact
 constexpr int MST_GLOBAL_ROOT_BLOCKS = 1792;  // workgroups (= private score matrices) of the root kernel in that mode: 7 per CU
@@ -99,7 +114,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
   double* S = m.S;
   const int ld = m.ld;
   for (int k = lane; k < n; k += 64) { m.order[k] = (uint8_t)k; m.pos[k] = (uint8_t)k; m.alive[k] = 1; }
-  __syncthreads();
+  MST_SYNC();
   int cur = n;       // nodes at this level
   int rec_end = 0;   // bytes of records written
   int levels = 0;
@@ -119,7 +134,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
         m.tree[k] = (uint8_t)scan_row(m, S + (size_t)k * ld, cur);
       }
     }
-    __syncthreads();
+    MST_SYNC();
     // ---- 2. cycles by pointer doubling: p = f^(2^r), mn = smallest logical position on the walk
     for (int li = lane; li < cur; li += 64) {
       const int k = m.order[li];
@@ -127,7 +142,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       m.mn0[k] = (uint8_t)li;
       m.flag[k] = 0;
     }
-    __syncthreads();
+    MST_SYNC();
     uint8_t *pa = m.p0, *pb = m.p1, *ma = m.mn0, *mb = m.mn1;
     for (int span = 1; span < cur; span <<= 1) {
       for (int li = lane; li < cur; li += 64) {
@@ -136,12 +151,12 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
         pb[k] = pa[q];
         mb[k] = min(ma[k], ma[q]);
       }
-      __syncthreads();
+      MST_SYNC();
       uint8_t* t = pa; pa = pb; pb = t;
       t = ma; ma = mb; mb = t;
     }
     for (int li = lane; li < cur; li += 64) m.flag[pa[m.order[li]]] = 1;  // eventual image = nodes on loops
-    __syncthreads();
+    MST_SYNC();
     int chosen = -1;
     for (int li = lane; li < cur; li += 64) {
       const int k = m.order[li];
@@ -168,7 +183,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       nn += __popcll(bn);
     }
     uint8_t* norder = m.p1;
-    __syncthreads();
+    MST_SYNC();
     const int slot_m = m.clist[0];
     // rank of each survivor among surviving slots in ascending slot id (record addressing)
     {
@@ -198,7 +213,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       rec[2 + c + i] = m.tree[k];
       m.cs[i] = S[(size_t)k * ld + m.tree[k]];
     }
-    __syncthreads();
+    MST_SYNC();
     // ---- 4. product of the cycle's arc scores, in cycle order
     double total = 1.0;
     for (int i = 0; i < c; ++i) total = total * m.cs[i];
@@ -223,7 +238,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       rec_h[m.rankn[j]] = (uint8_t)hi;
       rec_d[m.rankn[j]] = (uint8_t)di;
     }
-    __syncthreads();
+    MST_SYNC();
     // ---- 6. contracted node takes the slot of the cycle's first node and goes last in the order
     for (int a = lane; a < nn; a += 64) {
       const int j = norder[a];
@@ -255,13 +270,13 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       m.order[nn] = (uint8_t)slot_m;
       m.pos[slot_m] = (uint8_t)nn;
     }
-    __syncthreads();
+    MST_SYNC();
     cur = nn + 1;
     rec_end += need;
     ++levels;
   }
   // ---- expansion, deepest level first (utils.py:491-518)
-  __syncthreads();
+  MST_SYNC();
   int off_stack_end = rec_end;
   // records are variable length: walk forward once to find offsets is O(levels^2) if repeated,
   // so walk backwards using the stored sizes: each record's length is 2 + 2*m - ... recomputed
@@ -276,7 +291,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       ++l;
     }
   }
-  __syncthreads();
+  MST_SYNC();
   (void)off_stack_end;
   for (int l = levels - 1; l >= 0; --l) {
     const uint8_t* rec = m.rec + offs[l];
@@ -288,7 +303,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
     const uint8_t* rec_d = rec_h + nn;
     const int slot_m = cl[0];
     const int head_m = m.tree[slot_m];
-    __syncthreads();
+    MST_SYNC();
     int run = 0, rank_head = 0;
     for (int base = 0; base < n; base += 64) {
       const int s = base + lane;
@@ -300,11 +315,11 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       if (head_m >= base && head_m < base + 64) rank_head = run + __popcll(bm & ((head_m - base) == 0 ? 0ull : (~0ull >> (64 - (head_m - base)))));
       run += __popcll(bm);
     }
-    __syncthreads();
+    MST_SYNC();
     for (int i = lane; i < c; i += 64) { m.tree[cl[i]] = tc[i]; m.alive[cl[i]] = 1; }
-    __syncthreads();
+    MST_SYNC();
     if (lane == 0) m.tree[cl[rec_h[rank_head]]] = (uint8_t)head_m;
-    __syncthreads();
+    MST_SYNC();
   }
   return true;
 }
@@ -339,7 +354,7 @@ __device__ inline void build_scores(const MstLds& m, const float* p, int n, int 
       }
     }
   }
-  __syncthreads();
+  MST_SYNC();
 }
 
 struct MstWs {
@@ -384,11 +399,16 @@ __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
 }
 
 template <bool GS>  // GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words)
-__global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
-                                                       int B, int L, int32_t* heads, int32_t* status, MstWs ws) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel(const float* __restrict__ probs,
+                                                                       const int32_t* __restrict__ lens, int B, int L,
+                                                                       int32_t* heads, int32_t* status, MstWs ws,
+                                                                       int lds_task) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  unsigned char* const smem = smem_all + (size_t)wave * lds_task;
+  const int b = blockIdx.x * wpb + wave;
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
   const int T = L + 1;
   int len = lens[b];
   len = min(max(len, 0), L);
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
   MstLds m = mst_carve(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr);
   build_scores(m, p, n, T, lane, 0);
   if (!cle_run(m, n, lane)) { if (lane == 0) status[b] = 2; return; }
-  __syncthreads();
+  MST_SYNC();
   // roots (utils.py:525-534)
   int nroots = 0;
   for (int base = 1; base < n; base += 64) {
@@ -426,7 +446,7 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
       ncand += __popcll(__ballot(ok));
     }
     if (ncand == 0) {  // 1 + argmax(scores[1:, 0]), first maximum
-      __syncthreads();
+      MST_SYNC();
       if (lane == 0) {
         float best = p[0];
         int bi = 1;
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
       ncand = 1;
     }
   }
-  __syncthreads();
+  MST_SYNC();
   int base_task = 0;
   if (lane == 0) {
     base_task = atomicAdd(ws.ntasks, ncand);
@@ -464,26 +484,29 @@ __global__ __launch_bounds__(64) void mst_first_kernel(const float* __restrict__
 }
 
 template <bool GS>
-__global__ __launch_bounds__(64) void mst_root_kernel(const float* __restrict__ probs, const int32_t* __restrict__ lens,
-                                                      int B, int L, MstWs ws) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
+                                                                      const int32_t* __restrict__ lens, int B, int L, MstWs ws,
+                                                                      int lds_task) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  unsigned char* const smem = smem_all + (size_t)wave * lds_task;
+  const int lane = threadIdx.x & 63;
   const int T = L + 1;
   const int ntasks = min(*ws.ntasks, B * L);
-  for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
-    __syncthreads();
+  for (int t = blockIdx.x * wpb + wave; t < ntasks; t += gridDim.x * wpb) {
+    MST_SYNC();
     const int b = ws.task_sent[t];
     const int root = ws.task_root[t];
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
-    MstLds m = mst_carve(smem, n, GS ? ws.s_root + (size_t)blockIdx.x * T * (T | 1) : nullptr);
+    MstLds m = mst_carve(smem, n, GS ? ws.s_root + (size_t)(blockIdx.x * wpb + wave) * T * (T | 1) : nullptr);
     build_scores(m, p, n, T, lane, root);
     uint8_t* tt = ws.task_tree + (size_t)t * T;
     if (!cle_run(m, n, lane)) {
       if (lane == 0) ws.task_score[t] = -INFINITY;
       continue;
     }
-    __syncthreads();
+    MST_SYNC();
     // tree score (utils.py:551-552): sum of log of the selected entries of the set_root matrix
     double s = 0.0;
     bool all_nz = true;
@@ -542,7 +565,15 @@ namespace {
 int mst_decode_impl(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
                     void* workspace, hipStream_t st) {
   const bool gs_first = L + 1 > MST_MAX_N, gs_root = L + 1 >= MST_ROOT_GLOBAL_N;
-  const size_t lds_first = mst_lds_bytes(L + 1, gs_first), lds_root = mst_lds_bytes(L + 1, gs_root);
+  const size_t task_first = (mst_lds_bytes(L + 1, gs_first) + 15) & ~(size_t)15, task_root = (mst_lds_bytes(L + 1, gs_root) + 15) & ~(size_t)15;
+  // tasks per workgroup: as many as the CU's LDS holds (workspace-resident matrices: one, their blocks index the workspace)
+  auto waves = [](size_t task, bool gs) {
+    if (gs) return 1;
+    const size_t w = ((size_t)160 * 1024) / task;
+    return (int)(w < 1 ? 1 : (w > (size_t)MST_MAX_WAVES ? (size_t)MST_MAX_WAVES : w));
+  };
+  const int w_first = waves(task_first, gs_first), w_root = waves(task_root, gs_root);
+  const size_t lds_first = task_first * w_first, lds_root = task_root * w_root;
   static CubeLdsReservation reserved[4];
   const void* fn_first = gs_first ? (const void*)mst_first_kernel<true> : (const void*)mst_first_kernel<false>;
   const void* fn_root = gs_root ? (const void*)mst_root_kernel<true> : (const void*)mst_root_kernel<false>;
@@ -550,17 +581,21 @@ int mst_decode_impl(const float* probs, const int32_t* lens, int B, int L, int32
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds_first > lds_root ? lds_first : lds_root);
   MstWs ws = mst_ws_carve(workspace, B, L);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
+  const dim3 g_first((B + w_first - 1) / w_first), b_first(64 * w_first);
   if (gs_first)
-    hipLaunchKernelGGL(mst_first_kernel<true>, dim3(B), dim3(64), lds_first, st, probs, lens, B, L, heads, status, ws);
+    hipLaunchKernelGGL(mst_first_kernel<true>, g_first, b_first, lds_first, st, probs, lens, B, L, heads, status, ws, (int)task_first);
   else
-    hipLaunchKernelGGL(mst_first_kernel<false>, dim3(B), dim3(64), lds_first, st, probs, lens, B, L, heads, status, ws);
+    hipLaunchKernelGGL(mst_first_kernel<false>, g_first, b_first, lds_first, st, probs, lens, B, L, heads, status, ws, (int)task_first);
   CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
   if (gs_root) {
-    hipLaunchKernelGGL(mst_root_kernel<true>, dim3((unsigned)mst_root_blocks(B, L)), dim3(64), lds_root, st, probs, lens, B, L, ws);
+    hipLaunchKernelGGL(mst_root_kernel<true>, dim3((unsigned)mst_root_blocks(B, L)), dim3(64), lds_root, st, probs, lens, B, L, ws,
+                       (int)task_root);
   } else {
-    int nblk = B * L;
-    if (nblk > 4096) nblk = 4096;
-    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64), lds_root, st, probs, lens, B, L, ws);
+    // one task per candidate root, at most B*L of them; the grid strides over the device-side count
+    int nblk = (B * L + w_root - 1) / w_root;
+    const int cap = w_root > 1 ? MST_ROOT_MAX_BLOCKS : 4096;
+    if (nblk > cap) nblk = cap;
+    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws, (int)task_root);
   }
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
   hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
