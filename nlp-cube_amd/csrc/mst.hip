@@ -53,8 +53,8 @@ constexpr int MST_ROOT_GLOBAL_N = 96;  // workgroups (= private score matrices) 
 
 struct MstLds {
   double* S; int ld;
-  double* hval; double* dval; double* cs;
-  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn, *dlist;
+  double* hval; double* dval; double* cs; double* bval;
+  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn, *dlist, *tie;
   uint8_t* rec; int rec_cap;
 };
 
@@ -62,7 +62,7 @@ __host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
 __host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false) {
   const int ld = n | 1;
   const int np = mst_np(n);
-  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)3 * np * 8 + (size_t)13 * np + (size_t)(n * n + 3 * n + 16);
+  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)4 * np * 8 + (size_t)14 * np + (size_t)(n * n + 3 * n + 16);
 }
 
 __device__ inline MstLds mst_carve(unsigned char* smem, int n, double* global_s = nullptr) {
@@ -74,8 +74,9 @@ __device__ inline MstLds mst_carve(unsigned char* smem, int n, double* global_s 
   m.hval = reinterpret_cast<double*>(q); q += np * 8;
   m.dval = reinterpret_cast<double*>(q); q += np * 8;
   m.cs = reinterpret_cast<double*>(q); q += np * 8;
-  uint8_t** arr[13] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn, &m.dlist};
-  for (int i = 0; i < 13; ++i) { *arr[i] = q; q += np; }
+  m.bval = reinterpret_cast<double*>(q); q += np * 8;
+  uint8_t** arr[14] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn, &m.dlist, &m.tie};
+  for (int i = 0; i < 14; ++i) { *arr[i] = q; q += np; }
   m.rec = q;
   m.rec_cap = n * n + 3 * n + 16;
   return m;
@@ -87,12 +88,13 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-// First maximum of one row over the current nodes in logical order (NaN counts as maximal, like
-// numpy.argmax).  The two dependent LDS reads per entry (order list, then the score) are issued
-// eight entries at a time: a one-entry-at-a-time loop pays the full LDS latency per entry.
-__device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int cur) {
+// First maximum of one row over the current nodes in logical order, exactly like numpy.argmax (NaN counts as
+// maximal, the first one wins).  The two dependent reads per entry (order list, then the score) are issued eight
+// entries at a time: a one-entry-at-a-time loop pays the full latency per entry.  `bv` = the maximum, `tie` = some
+// other entry equals it (or it is NaN): see cle_run, step 1.
+__device__ __forceinline__ int scan_row_exact(const MstLds& m, const double* row, int cur, double& bv, int& tie) {
   double best = row[m.order[0]];
-  int bi = m.order[0];
+  int bi = m.order[0], t = 0;
   for (int l0 = 1; l0 < cur; l0 += 8) {
     int j[8];
     double v[8];
@@ -102,15 +104,59 @@ __device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int 
     for (int u = 0; u < 8; ++u) v[u] = row[j[u]];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (l0 + u < cur && (v[u] > best || (v[u] != v[u] && best == best))) { best = v[u]; bi = j[u]; }
+      if (l0 + u < cur) {
+        if (v[u] > best || (v[u] != v[u] && best == best)) { best = v[u]; bi = j[u]; t = 0; }
+        else if (v[u] == best) t = 1;
+      }
   }
+  bv = best;
+  tie = (t || best != best) ? 1 : 0;
+  return bi;
+}
+
+// The same for a matrix without NaNs (cle_run keeps track): one ordered compare per entry, and the order list is
+// read eight bytes at a time (it is 8-byte aligned and padded to a multiple of 8 bytes).
+template <bool MASK>
+__device__ __forceinline__ void scan8(const MstLds& m, const double* row, int l0, int cur, double& best, int& bi, int& t) {
+  const uint64_t w = *reinterpret_cast<const uint64_t*>(m.order + l0);
+  int j[8];
+  double v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    j[u] = (int)((w >> (8 * u)) & 255u);
+    if (MASK && !(l0 + u >= 1 && l0 + u < cur)) j[u] = 0;  // bytes past the list are stale: read a slot that exists
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = row[j[u]];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = !MASK || (l0 + u >= 1 && l0 + u < cur);
+    const bool upd = ok && v[u] > best;
+    const bool eq = ok && v[u] == best;
+    t = upd ? 0 : (t | (eq ? 1 : 0));
+    best = upd ? v[u] : best;
+    bi = upd ? j[u] : bi;
+  }
+}
+
+__device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int cur, bool has_nan, double& bv, int& tie) {
+  if (has_nan) return scan_row_exact(m, row, cur, bv, tie);
+  double best = row[m.order[0]];
+  int bi = m.order[0], t = 0;
+  scan8<true>(m, row, 0, cur, best, bi, t);  // entry 0 is the start value: masked out
+  int l0 = 8;
+  for (; l0 + 8 <= cur; l0 += 8) scan8<false>(m, row, l0, cur, best, bi, t);
+  if (l0 < cur) scan8<true>(m, row, l0, cur, best, bi, t);
+  bv = best;
+  tie = t;
   return bi;
 }
 
 // Runs the contraction/expansion on the n x n matrix in `m.S` (row = dependent, column = head;
 // row 0 is virtual: e_0).  Diagonal entries must be zero on entry.  Result: m.tree[k] = head.
 // Returns false if the record area overflowed (cannot happen for n <= MST_MAX_N).
-__device__ bool cle_run(const MstLds& m, int n, int lane) {
+// `has_nan`: the matrix holds a NaN (wave-uniform; build_scores reports it, step 5 keeps it up to date).
+__device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
   double* S = m.S;
   const int ld = m.ld;
   for (int k = lane; k < n; k += 64) { m.order[k] = (uint8_t)k; m.pos[k] = (uint8_t)k; m.alive[k] = 1; }
@@ -120,18 +166,26 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
   int levels = 0;
   int ndirty = 0;    // rows whose best head must be re-scanned at the next level
   while (true) {
-    // ---- 1. best head per node, first maximum in logical order.  First level: every row, one row
-    // per lane.  Later levels: only the rows whose arg-max can have changed — the contracted node's
-    // row and the rows whose best head was a node of the contracted cycle (`dlist`); for every other
-    // row the old best head survives, keeps its value and still precedes every equal entry (the
-    // survivors keep their relative order, the contracted node goes last), so a full re-scan would
-    // return it again.  One row per lane, eight entries in flight per lane.
+    // ---- 1. best head per node, first maximum in logical order.  First level: every row, one row per lane, eight
+    // entries in flight per lane.  Later levels: a row's arg-max can only change if its best head was a node of the
+    // contracted cycle (for every other row the old best head survives, keeps its value and still precedes every
+    // equal entry: the survivors keep their relative order and the contracted node goes last).  Such a row's maximum
+    // V was attained inside the cycle, so its entry for the contracted node -- the largest of its entries into the
+    // cycle -- is V again and every surviving entry is <= V: the new best head is the first survivor equal to V or,
+    // if there is none, the contracted node.  `tie[k]` says whether row k holds a second entry equal to its maximum
+    // (kept conservatively: set by the scans and when a new entry equals the maximum, never cleared by removals), so
+    // the common case needs no scan at all (step 6 re-points the row) and only rows with a tie are scanned again
+    // (`dlist`).  The contracted node's own row is scanned in step 6 from the values it was built from.
     {
       const int nscan = (levels == 0) ? cur : ndirty;
       for (int li = lane; li < nscan; li += 64) {
         const int k = (levels == 0) ? m.order[li] : m.dlist[li];
         if (k == 0) { m.tree[0] = 0; continue; }
-        m.tree[k] = (uint8_t)scan_row(m, S + (size_t)k * ld, cur);
+        double bv;
+        int tie;
+        m.tree[k] = (uint8_t)scan_row(m, S + (size_t)k * ld, cur, has_nan, bv, tie);
+        m.bval[k] = bv;
+        m.tie[k] = (uint8_t)tie;
       }
     }
     MST_SYNC();
@@ -220,6 +274,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
     // ---- 5. best entry/exit of the contracted node per surviving node
     uint8_t* rec_h = rec + 2 + 2 * c;
     uint8_t* rec_d = rec_h + nn;
+    bool new_nan = false;
     for (int a = lane; a < nn; a += 64) {
       const int j = norder[a];
       double hb = S[(size_t)m.clist[0] * ld + j] / m.cs[0] * total;
@@ -237,7 +292,9 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       m.dval[a] = db;
       rec_h[m.rankn[j]] = (uint8_t)hi;
       rec_d[m.rankn[j]] = (uint8_t)di;
+      new_nan |= (hb != hb);
     }
+    has_nan = has_nan || (__ballot(new_nan) != 0ull);  // 0/0 or inf*0 in the entry scores of this contraction
     MST_SYNC();
     // ---- 6. contracted node takes the slot of the cycle's first node and goes last in the order
     for (int a = lane; a < nn; a += 64) {
@@ -247,23 +304,61 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
       m.order[a] = (uint8_t)j;
       m.pos[j] = (uint8_t)a;
     }
-    // rows to re-scan: survivors whose best head sat in the cycle, and the contracted node itself
+    // rows whose best head sat in the cycle (step 1): without a tie they now point at the contracted node, with one
+    // they are scanned again; for every other row the new entry may have created a tie with its maximum.  With a NaN
+    // in the matrix (now or before this level: the flags then predate it) every such row is scanned, exactly.
     ndirty = 0;
     for (int base = 0; base < nn; base += 64) {
       const int a = base + lane;
       int j = 0;
-      bool dty = false;
+      bool dty = false, rescan = false;
       if (a < nn) {
         j = norder[a];
         dty = (j != 0) && m.incyc[m.tree[j]];
+        if (dty) {
+          rescan = has_nan || m.tie[j];
+          if (!rescan) m.tree[j] = (uint8_t)slot_m;
+        } else if (j != 0 && !(m.dval[a] < m.bval[j])) {
+          m.tie[j] = 1;
+        }
       }
-      const unsigned long long bd = __ballot(dty);
+      const unsigned long long bd = __ballot(rescan);
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      if (dty) m.dlist[ndirty + __popcll(bd & below)] = (uint8_t)j;
+      if (rescan) m.dlist[ndirty + __popcll(bd & below)] = (uint8_t)j;
       ndirty += __popcll(bd);
     }
-    if (lane == 0) m.dlist[ndirty] = (uint8_t)slot_m;
-    ++ndirty;
+    // the contracted node's row = hval[0 .. nn) in the new logical order, then its zero diagonal: all lanes scan it
+    // together (first maximum: larger value, then smaller position), no order list and no trip through S
+    if (has_nan) {
+      if (lane == 0) m.dlist[ndirty] = (uint8_t)slot_m;
+      ++ndirty;
+    } else {
+      constexpr int PER = (MST_MAX_N_GLOBAL + 63) / 64;
+      double v[PER];
+      double best = -INFINITY;
+      int bl = 1 << 20;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int l = lane + 64 * i;
+        v[i] = l < nn ? m.hval[l] : (l == nn ? 0.0 : -INFINITY);
+        if (l <= nn && v[i] > best) { best = v[i]; bl = l; }
+      }
+      if (bl == (1 << 20) && lane <= nn) bl = lane;  // all of this lane's entries are -inf: the first of them stands for them
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best, o);
+        const int ol = __shfl_xor(bl, o);
+        if (ov > best || (ov == best && ol < bl)) { best = ov; bl = ol; }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) cnt += __popcll(__ballot(lane + 64 * i <= nn && v[i] == best));
+      if (lane == 0) {
+        m.tree[slot_m] = bl < nn ? norder[bl] : (uint8_t)slot_m;
+        m.bval[slot_m] = best;
+        m.tie[slot_m] = cnt >= 2 ? 1 : 0;
+      }
+    }
     for (int i = 1 + lane; i < c; i += 64) m.alive[m.clist[i]] = 0;
     if (lane == 0) {
       S[(size_t)slot_m * ld + slot_m] = 0.0;
@@ -325,7 +420,9 @@ __device__ bool cle_run(const MstLds& m, int n, int lane) {
 }
 
 // S[k][j] for k >= 1 from the probability tensor (utils.py:569-574): crop to n columns, zero diagonal
-__device__ inline void build_scores(const MstLds& m, const float* p, int n, int T, int lane, int root) {
+// Returns whether the matrix holds a NaN (wave-uniform).
+__device__ inline bool build_scores(const MstLds& m, const float* p, int n, int T, int lane, int root) {
+  bool nan = false;
   // flattened over (k, j) with 8 independent loads in flight per lane (a row-by-row loop pays one
   // global-load latency per row: ~130 us of a 129-node task)
   const int total = (n - 1) * n;
@@ -351,10 +448,12 @@ __device__ inline void build_scores(const MstLds& m, const float* p, int n, int 
           else if (k == root) d = 0.0;
         }
         m.S[(size_t)k * m.ld + j] = d;
+        nan |= (d != d);
       }
     }
   }
   MST_SYNC();
+  return __ballot(nan) != 0ull;
 }
 
 struct MstWs {
@@ -419,8 +518,8 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
   if (len == 0) return;
   const float* p = probs + (size_t)b * L * T;
   MstLds m = mst_carve(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr);
-  build_scores(m, p, n, T, lane, 0);
-  if (!cle_run(m, n, lane)) { if (lane == 0) status[b] = 2; return; }
+  const bool has_nan = build_scores(m, p, n, T, lane, 0);
+  if (!cle_run(m, n, lane, has_nan)) { if (lane == 0) status[b] = 2; return; }
   MST_SYNC();
   // roots (utils.py:525-534)
   int nroots = 0;
@@ -500,9 +599,9 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
     MstLds m = mst_carve(smem, n, GS ? ws.s_root + (size_t)(blockIdx.x * wpb + wave) * T * (T | 1) : nullptr);
-    build_scores(m, p, n, T, lane, root);
+    const bool has_nan = build_scores(m, p, n, T, lane, root);
     uint8_t* tt = ws.task_tree + (size_t)t * T;
-    if (!cle_run(m, n, lane)) {
+    if (!cle_run(m, n, lane, has_nan)) {
       if (lane == 0) ws.task_score[t] = -INFINITY;
       continue;
     }

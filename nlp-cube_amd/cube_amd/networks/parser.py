@@ -657,7 +657,7 @@ class Parser(_HipNet):
     def _encode(self, bt, want_aux=False, slot=0):
         return self._back(bt, self._front(bt, slot, want_aux), slot)
 
-    def _label_scores(self, bt, pp, pp_w, heads_dev, labels_out=None, hl=None, hl_w=0, hl_col=0):
+    def _label_scores(self, bt, pp, pp_w, heads_dev, labels_out=None, hl=None, hl_w=0, hl_col=0, slot=0):
         """parser.py:218-233: gather head rows + DeepBiaffine(pairwise=False), fused on device.
         hl (with its leading dimension and first column): the [x1;1 | x2;1] projections when the encode
         stage has already made them (`_back`); else they are computed here from `pp`."""
@@ -671,7 +671,7 @@ class Parser(_HipNet):
             hip.gemm(pp, pp_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_RELU, out0=hl, ldo0=2 * Dl,
                      n_valid=2 * Dl, stream=st)
         n_l = self._sizes["labels"]
-        logits = self._buf.get("label_logits", B * L, n_l, torch.float32)[:B * L * n_l].view(B, L, n_l)
+        logits = self._buf.get("label_logits_%d" % slot, B * L, n_l, torch.float32)[:B * L * n_l].view(B, L, n_l)
         labels = labels_out if labels_out is not None else \
             self._buf.get("labels", B, L, torch.int32)[:B * L].view(B, L)
         lb = pk["label_bilin"]
@@ -689,12 +689,12 @@ class Parser(_HipNet):
         packed = self._buf.get("packed_%d" % slot, 5, B * L, torch.int32)[:5 * B * L].view(5, B, L)
         status = self._buf.get("status_%d" % slot, 1, B, torch.int32)[:B]
         ws_bytes = hip.load().cube_mst_workspace_bytes(B, L)
-        ws = self._buf.get("mst_ws", 1, (ws_bytes + 7) // 8, torch.int64)
+        ws = self._buf.get("mst_ws_%d" % slot, 1, (ws_bytes + 7) // 8, torch.int64)
         hip.check(hip.load().cube_mst_decode(r["arc_probs"].data_ptr(), bt["lens"].data_ptr(), B, L,
                                              packed[0].data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                              hip.stream_handle()), "cube_mst_decode")
         label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], packed[0], labels_out=packed[1],
-                                                  hl=r["hal"], hl_w=r["hal_w"], hl_col=r["hl_col"])
+                                                  hl=r["hal"], hl_w=r["hal_w"], hl_col=r["hl_col"], slot=slot)
         packed[2].copy_(r["upos"])
         packed[3].copy_(r["xpos"])
         packed[4].copy_(r["attrs"])
@@ -762,7 +762,8 @@ class Parser(_HipNet):
         may be in flight (submitted, not collected)."""
         self._require_gpu()
         if self._streams is None:
-            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
+            n3 = self.N_SLOTS if os.environ.get("CUBE_STAGE3_STREAMS", "1") != "0" else 1
+            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(2 + n3))
             self._slot_free = [None] * self.N_SLOTS
             self._host_res = [None] * self.N_SLOTS
             self._slot_busy = [False] * self.N_SLOTS
@@ -775,7 +776,8 @@ class Parser(_HipNet):
             raise hip.CubeHipError("Parser.submit: %d batches are in flight, collect() the oldest first" % self.N_SLOTS)
         self._slot_busy[slot] = True
         self._n_submitted += 1
-        s1, s2, s3 = self._streams
+        s1, s2 = self._streams[:2]
+        s3 = self._streams[2 + slot % (len(self._streams) - 2)]  # the decode stage of each slot on a stream of its own
         cur = torch.cuda.current_stream()
         B, L = bt["B"], bt["L"]
         with torch.cuda.stream(s1):

@@ -237,6 +237,46 @@ def test_mst_long_sentences_match_oracle(dev):
         dec.decode(np.full((1, 255, 256), 1.0 / 256, dtype=np.float32), np.array([255]))
 
 
+def test_mst_ties_and_zeros_match_oracle(dev):
+    """Quantised probabilities (many exactly equal entries: every first-maximum tie-break counts, and the kernel's
+    per-row tie flags decide which rows are scanned again after a contraction) and rows with exact zeros (0/0 = NaN
+    entry scores inside the contraction) against the NumPy restatement of the reference decoder."""
+    from oracle import cle_oracle
+    from cube_amd.networks.utils import ChuLiuEdmondsDecoder
+    dec = ChuLiuEdmondsDecoder(dev)
+    rng = np.random.default_rng(23)
+    n_checked = n_near_ties = 0
+    for L, B, levels, zero_frac in ((12, 16, 4, 0.0), (40, 8, 8, 0.0), (100, 4, 16, 0.0), (128, 3, 6, 0.0),
+                                    (16, 16, 4, 0.5), (48, 8, 8, 0.7), (100, 3, 5, 0.8)):
+        q = rng.integers(1, levels + 1, size=(B, L, L + 1)).astype(np.float32)
+        q[rng.random(q.shape) < zero_frac] = 0.0
+        q[:, :, 0] = np.maximum(q[:, :, 0], 1.0) * (rng.random((B, L)) < 0.3)  # few root candidates, never none at all
+        q[:, 0, 0] = 1.0
+        probs = (q / 64.0).astype(np.float32)
+        lens = np.array([L] + [int(rng.integers(2, L + 1)) for _ in range(B - 1)], dtype=np.int64)
+        probs_d = torch.from_numpy(probs).to(dev)
+        heads, status = dec.decode_device(probs_d, torch.from_numpy(lens.astype(np.int32)).to(dev))
+        heads, status = heads.cpu().numpy(), status.cpu().numpy()
+        for b in range(B):
+            try:
+                with np.errstate(all="ignore"):
+                    exp = cle_oracle.decode(probs[b:b + 1], lens[b:b + 1])[0]
+            except cle_oracle.NoTreeError:
+                assert status[b] != 0, "L=%d b=%d: the oracle finds no tree" % (L, b)
+                continue
+            assert status[b] == 0, "L=%d b=%d" % (L, b)
+            got = heads[b, :lens[b]]
+            if not np.array_equal(got, exp):
+                # equal products of quantised probabilities: two candidate roots whose log-scores differ in the last
+                # bit of the sum (the reference's own comparison is decided by summation order there)
+                rows = np.arange(lens[b])
+                sc_got, sc_exp = (np.log(probs[b][rows, h].astype(np.float64)).sum() for h in (got, exp))
+                assert (got == 0).sum() == 1 and abs(sc_got - sc_exp) <= 1e-12 * abs(sc_exp), "L=%d b=%d" % (L, b)
+                n_near_ties += 1
+            n_checked += 1
+    assert n_checked >= 20 and n_near_ties <= 3
+
+
 # ------------------------------------------------------------------------------------------
 # whole path: bf16x3 against the REFERENCE's outputs (golden) and the fp32 oracle;
 #             bf16 (single pass) against the bf16-contract oracle
