@@ -42,7 +42,9 @@ constexpr int MST_MAX_WAVES = 16;
 constexpr int MST_ROOT_MAX_BLOCKS = 96;  // CUs the rooted re-runs may spread over when tasks are packed
 
 constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
-constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences (node ids are bytes): S lives in the workspace (HBM/L2), slow but exact
+constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences, node ids still bytes: S lives in the workspace (HBM/L2), slow but exact
+constexpr int MST_MAX_N_LONG = 2048;   // beyond 254 words: 16-bit node ids, S and the contraction records in the workspace
+constexpr size_t MST_LONG_ROOT_BYTES = (size_t)2 << 30;  // workspace the rooted re-runs of such a batch may take
 constexpr int MST_GLOBAL_ROOT_BLOCKS = 1792;  // workgroups (= private score matrices) of the root kernel in that mode: 7 per CU
 // The rooted re-runs (one task per candidate root, ~17 per sentence when most first trees are not
 // single-rooted) switch to workspace-resident score matrices earlier: from this size on an LDS-resident
@@ -51,22 +53,26 @@ constexpr int MST_GLOBAL_ROOT_BLOCKS = 1792;  // workgroups (= private score mat
 // with S in the workspace; the first pass, one task per sentence, stays in LDS)
 constexpr int MST_ROOT_GLOBAL_N = 96;  // workgroups (= private score matrices) of the root kernel in that mode
 
-struct MstLds {
+template <typename IdT>  // node ids: bytes up to 254 words, 16 bits beyond
+struct MstLdsT {
   double* S; int ld;
   double* hval; double* dval; double* cs; double* bval;
-  uint8_t *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn, *dlist, *tie;
-  uint8_t* rec; int rec_cap;
+  IdT *order, *pos, *tree, *p0, *p1, *mn0, *mn1, *flag, *incyc, *alive, *clist, *rankn, *dlist, *tie;
+  IdT* rec; int rec_cap;
 };
 
 __host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
-__host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false) {
+__host__ __device__ inline size_t mst_rec_cap(int n) { return (size_t)n * n + 3 * (size_t)n + 16; }
+// LDS of one task; `id` = bytes per node id; 2-byte ids keep their contraction records in the workspace as well
+__host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false, int id = 1) {
   const int ld = n | 1;
   const int np = mst_np(n);
-  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)4 * np * 8 + (size_t)14 * np + (size_t)(n * n + 3 * n + 16);
+  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)4 * np * 8 + (size_t)14 * np * id + (id == 1 ? mst_rec_cap(n) : 0);
 }
 
-__device__ inline MstLds mst_carve(unsigned char* smem, int n, double* global_s = nullptr) {
-  MstLds m;
+template <typename IdT>
+__device__ inline MstLdsT<IdT> mst_carve(unsigned char* smem, int n, double* global_s = nullptr, IdT* global_rec = nullptr) {
+  MstLdsT<IdT> m;
   const int np = mst_np(n);
   m.ld = n | 1;
   m.S = global_s ? global_s : reinterpret_cast<double*>(smem);
@@ -75,10 +81,10 @@ __device__ inline MstLds mst_carve(unsigned char* smem, int n, double* global_s 
   m.dval = reinterpret_cast<double*>(q); q += np * 8;
   m.cs = reinterpret_cast<double*>(q); q += np * 8;
   m.bval = reinterpret_cast<double*>(q); q += np * 8;
-  uint8_t** arr[14] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn, &m.dlist, &m.tie};
-  for (int i = 0; i < 14; ++i) { *arr[i] = q; q += np; }
-  m.rec = q;
-  m.rec_cap = n * n + 3 * n + 16;
+  IdT** arr[14] = {&m.order, &m.pos, &m.tree, &m.p0, &m.p1, &m.mn0, &m.mn1, &m.flag, &m.incyc, &m.alive, &m.clist, &m.rankn, &m.dlist, &m.tie};
+  for (int i = 0; i < 14; ++i) { *arr[i] = reinterpret_cast<IdT*>(q); q += np * sizeof(IdT); }
+  m.rec = global_rec ? global_rec : reinterpret_cast<IdT*>(q);
+  m.rec_cap = (int)mst_rec_cap(n);
   return m;
 }
 
@@ -92,7 +98,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // maximal, the first one wins).  The two dependent reads per entry (order list, then the score) are issued eight
 // entries at a time: a one-entry-at-a-time loop pays the full latency per entry.  `bv` = the maximum, `tie` = some
 // other entry equals it (or it is NaN): see cle_run, step 1.
-__device__ __forceinline__ int scan_row_exact(const MstLds& m, const double* row, int cur, double& bv, int& tie) {
+template <typename IdT>
+__device__ __forceinline__ int scan_row_exact(const MstLdsT<IdT>& m, const double* row, int cur, double& bv, int& tie) {
   double best = row[m.order[0]];
   int bi = m.order[0], t = 0;
   for (int l0 = 1; l0 < cur; l0 += 8) {
@@ -116,14 +123,17 @@ __device__ __forceinline__ int scan_row_exact(const MstLds& m, const double* row
 
 // The same for a matrix without NaNs (cle_run keeps track): one ordered compare per entry, and the order list is
 // read eight bytes at a time (it is 8-byte aligned and padded to a multiple of 8 bytes).
-template <bool MASK>
-__device__ __forceinline__ void scan8(const MstLds& m, const double* row, int l0, int cur, double& best, int& bi, int& t) {
-  const uint64_t w = *reinterpret_cast<const uint64_t*>(m.order + l0);
+template <bool MASK, typename IdT>
+__device__ __forceinline__ void scan8(const MstLdsT<IdT>& m, const double* row, int l0, int cur, double& best, int& bi, int& t) {
+  constexpr int PW = 8 / sizeof(IdT);  // ids per 8-byte word
+  uint64_t w[sizeof(IdT)];
+#pragma unroll
+  for (int i = 0; i < (int)sizeof(IdT); ++i) w[i] = reinterpret_cast<const uint64_t*>(m.order + l0)[i];
   int j[8];
   double v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    j[u] = (int)((w >> (8 * u)) & 255u);
+    j[u] = (int)((w[u / PW] >> (8 * sizeof(IdT) * (u % PW))) & (sizeof(IdT) == 1 ? 0xffu : 0xffffu));
     if (MASK && !(l0 + u >= 1 && l0 + u < cur)) j[u] = 0;  // bytes past the list are stale: read a slot that exists
   }
 #pragma unroll
@@ -139,14 +149,15 @@ __device__ __forceinline__ void scan8(const MstLds& m, const double* row, int l0
   }
 }
 
-__device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int cur, bool has_nan, double& bv, int& tie) {
+template <typename IdT>
+__device__ __forceinline__ int scan_row(const MstLdsT<IdT>& m, const double* row, int cur, bool has_nan, double& bv, int& tie) {
   if (has_nan) return scan_row_exact(m, row, cur, bv, tie);
   double best = row[m.order[0]];
   int bi = m.order[0], t = 0;
-  scan8<true>(m, row, 0, cur, best, bi, t);  // entry 0 is the start value: masked out
+  scan8<true, IdT>(m, row, 0, cur, best, bi, t);  // entry 0 is the start value: masked out
   int l0 = 8;
-  for (; l0 + 8 <= cur; l0 += 8) scan8<false>(m, row, l0, cur, best, bi, t);
-  if (l0 < cur) scan8<true>(m, row, l0, cur, best, bi, t);
+  for (; l0 + 8 <= cur; l0 += 8) scan8<false, IdT>(m, row, l0, cur, best, bi, t);
+  if (l0 < cur) scan8<true, IdT>(m, row, l0, cur, best, bi, t);
   bv = best;
   tie = t;
   return bi;
@@ -156,10 +167,11 @@ __device__ __forceinline__ int scan_row(const MstLds& m, const double* row, int 
 // row 0 is virtual: e_0).  Diagonal entries must be zero on entry.  Result: m.tree[k] = head.
 // Returns false if the record area overflowed (cannot happen for n <= MST_MAX_N).
 // `has_nan`: the matrix holds a NaN (wave-uniform; build_scores reports it, step 5 keeps it up to date).
-__device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
+template <typename IdT>
+__device__ bool cle_run(const MstLdsT<IdT>& m, int n, int lane, bool has_nan) {
   double* S = m.S;
   const int ld = m.ld;
-  for (int k = lane; k < n; k += 64) { m.order[k] = (uint8_t)k; m.pos[k] = (uint8_t)k; m.alive[k] = 1; }
+  for (int k = lane; k < n; k += 64) { m.order[k] = (IdT)k; m.pos[k] = (IdT)k; m.alive[k] = 1; }
   MST_SYNC();
   int cur = n;       // nodes at this level
   int rec_end = 0;   // bytes of records written
@@ -183,9 +195,9 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
         if (k == 0) { m.tree[0] = 0; continue; }
         double bv;
         int tie;
-        m.tree[k] = (uint8_t)scan_row(m, S + (size_t)k * ld, cur, has_nan, bv, tie);
+        m.tree[k] = (IdT)scan_row(m, S + (size_t)k * ld, cur, has_nan, bv, tie);
         m.bval[k] = bv;
-        m.tie[k] = (uint8_t)tie;
+        m.tie[k] = (IdT)tie;
       }
     }
     MST_SYNC();
@@ -193,11 +205,11 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
     for (int li = lane; li < cur; li += 64) {
       const int k = m.order[li];
       m.p0[k] = m.tree[k];
-      m.mn0[k] = (uint8_t)li;
+      m.mn0[k] = (IdT)li;
       m.flag[k] = 0;
     }
     MST_SYNC();
-    uint8_t *pa = m.p0, *pb = m.p1, *ma = m.mn0, *mb = m.mn1;
+    IdT *pa = m.p0, *pb = m.p1, *ma = m.mn0, *mb = m.mn1;
     for (int span = 1; span < cur; span <<= 1) {
       for (int li = lane; li < cur; li += 64) {
         const int k = m.order[li];
@@ -206,7 +218,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
         mb[k] = min(ma[k], ma[q]);
       }
       MST_SYNC();
-      uint8_t* t = pa; pa = pb; pb = t;
+      IdT* t = pa; pa = pb; pb = t;
       t = ma; ma = mb; mb = t;
     }
     for (int li = lane; li < cur; li += 64) m.flag[pa[m.order[li]]] = 1;  // eventual image = nodes on loops
@@ -231,12 +243,12 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
       }
       const unsigned long long bc = __ballot(in_c), bn = __ballot(in_n);
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      if (in_c) { m.clist[c + __popcll(bc & below)] = (uint8_t)k; m.incyc[k] = 1; }
-      if (in_n) { m.p1[nn + __popcll(bn & below)] = (uint8_t)k; m.incyc[k] = 0; }  // p1 reused: new order list
+      if (in_c) { m.clist[c + __popcll(bc & below)] = (IdT)k; m.incyc[k] = 1; }
+      if (in_n) { m.p1[nn + __popcll(bn & below)] = (IdT)k; m.incyc[k] = 0; }  // p1 reused: new order list
       c += __popcll(bc);
       nn += __popcll(bn);
     }
-    uint8_t* norder = m.p1;
+    IdT* norder = m.p1;
     MST_SYNC();
     const int slot_m = m.clist[0];
     // rank of each survivor among surviving slots in ascending slot id (record addressing)
@@ -247,7 +259,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
         const bool ok = (s < n) && m.alive[s] && !m.incyc[s];
         const unsigned long long bm = __ballot(ok);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        if (ok) m.rankn[s] = (uint8_t)(run + __popcll(bm & below));
+        if (ok) m.rankn[s] = (IdT)(run + __popcll(bm & below));
         run += __popcll(bm);
       }
     }
@@ -259,11 +271,11 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
     // negative entries (not probabilities: a caller's bug, an overwritten buffer) can produce the
     // self-loop c == 1, which would contract nothing and spin forever -- report "no tree" instead.
     if (c < 2 || levels >= n) return false;
-    uint8_t* rec = m.rec + rec_end;
-    if (lane == 0) { rec[0] = (uint8_t)cur; rec[1] = (uint8_t)c; }
+    IdT* rec = m.rec + rec_end;
+    if (lane == 0) { rec[0] = (IdT)cur; rec[1] = (IdT)c; }
     for (int i = lane; i < c; i += 64) {
       const int k = m.clist[i];
-      rec[2 + i] = (uint8_t)k;
+      rec[2 + i] = (IdT)k;
       rec[2 + c + i] = m.tree[k];
       m.cs[i] = S[(size_t)k * ld + m.tree[k]];
     }
@@ -272,8 +284,8 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
     double total = 1.0;
     for (int i = 0; i < c; ++i) total = total * m.cs[i];
     // ---- 5. best entry/exit of the contracted node per surviving node
-    uint8_t* rec_h = rec + 2 + 2 * c;
-    uint8_t* rec_d = rec_h + nn;
+    IdT* rec_h = rec + 2 + 2 * c;
+    IdT* rec_d = rec_h + nn;
     bool new_nan = false;
     for (int a = lane; a < nn; a += 64) {
       const int j = norder[a];
@@ -290,8 +302,8 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
       }
       m.hval[a] = hb;
       m.dval[a] = db;
-      rec_h[m.rankn[j]] = (uint8_t)hi;
-      rec_d[m.rankn[j]] = (uint8_t)di;
+      rec_h[m.rankn[j]] = (IdT)hi;
+      rec_d[m.rankn[j]] = (IdT)di;
       new_nan |= (hb != hb);
     }
     has_nan = has_nan || (__ballot(new_nan) != 0ull);  // 0/0 or inf*0 in the entry scores of this contraction
@@ -301,8 +313,8 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
       const int j = norder[a];
       S[(size_t)slot_m * ld + j] = m.hval[a];
       if (j != 0) S[(size_t)j * ld + slot_m] = m.dval[a];
-      m.order[a] = (uint8_t)j;
-      m.pos[j] = (uint8_t)a;
+      m.order[a] = (IdT)j;
+      m.pos[j] = (IdT)a;
     }
     // rows whose best head sat in the cycle (step 1): without a tie they now point at the contracted node, with one
     // they are scanned again; for every other row the new entry may have created a tie with its maximum.  With a NaN
@@ -317,31 +329,27 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
         dty = (j != 0) && m.incyc[m.tree[j]];
         if (dty) {
           rescan = has_nan || m.tie[j];
-          if (!rescan) m.tree[j] = (uint8_t)slot_m;
+          if (!rescan) m.tree[j] = (IdT)slot_m;
         } else if (j != 0 && !(m.dval[a] < m.bval[j])) {
           m.tie[j] = 1;
         }
       }
       const unsigned long long bd = __ballot(rescan);
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      if (rescan) m.dlist[ndirty + __popcll(bd & below)] = (uint8_t)j;
+      if (rescan) m.dlist[ndirty + __popcll(bd & below)] = (IdT)j;
       ndirty += __popcll(bd);
     }
     // the contracted node's row = hval[0 .. nn) in the new logical order, then its zero diagonal: all lanes scan it
     // together (first maximum: larger value, then smaller position), no order list and no trip through S
     if (has_nan) {
-      if (lane == 0) m.dlist[ndirty] = (uint8_t)slot_m;
+      if (lane == 0) m.dlist[ndirty] = (IdT)slot_m;
       ++ndirty;
     } else {
-      constexpr int PER = (MST_MAX_N_GLOBAL + 63) / 64;
-      double v[PER];
       double best = -INFINITY;
       int bl = 1 << 20;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int l = lane + 64 * i;
-        v[i] = l < nn ? m.hval[l] : (l == nn ? 0.0 : -INFINITY);
-        if (l <= nn && v[i] > best) { best = v[i]; bl = l; }
+      for (int l = lane; l <= nn; l += 64) {
+        const double v = l < nn ? m.hval[l] : 0.0;
+        if (v > best) { best = v; bl = l; }
       }
       if (bl == (1 << 20) && lane <= nn) bl = lane;  // all of this lane's entries are -inf: the first of them stands for them
 #pragma unroll
@@ -351,10 +359,13 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
         if (ov > best || (ov == best && ol < bl)) { best = ov; bl = ol; }
       }
       int cnt = 0;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) cnt += __popcll(__ballot(lane + 64 * i <= nn && v[i] == best));
+      for (int base = 0; base <= nn; base += 64) {
+        const int l = base + lane;
+        const double v = l < nn ? m.hval[l] : 0.0;
+        cnt += __popcll(__ballot(l <= nn && v == best));
+      }
       if (lane == 0) {
-        m.tree[slot_m] = bl < nn ? norder[bl] : (uint8_t)slot_m;
+        m.tree[slot_m] = bl < nn ? norder[bl] : (IdT)slot_m;
         m.bval[slot_m] = best;
         m.tie[slot_m] = cnt >= 2 ? 1 : 0;
       }
@@ -362,8 +373,8 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
     for (int i = 1 + lane; i < c; i += 64) m.alive[m.clist[i]] = 0;
     if (lane == 0) {
       S[(size_t)slot_m * ld + slot_m] = 0.0;
-      m.order[nn] = (uint8_t)slot_m;
-      m.pos[slot_m] = (uint8_t)nn;
+      m.order[nn] = (IdT)slot_m;
+      m.pos[slot_m] = (IdT)nn;
     }
     MST_SYNC();
     cur = nn + 1;
@@ -389,13 +400,13 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
   MST_SYNC();
   (void)off_stack_end;
   for (int l = levels - 1; l >= 0; --l) {
-    const uint8_t* rec = m.rec + offs[l];
+    const IdT* rec = m.rec + offs[l];
     const int mm = rec[0], c = rec[1];
     const int nn = mm - c;
-    const uint8_t* cl = rec + 2;
-    const uint8_t* tc = rec + 2 + c;
-    const uint8_t* rec_h = rec + 2 + 2 * c;
-    const uint8_t* rec_d = rec_h + nn;
+    const IdT* cl = rec + 2;
+    const IdT* tc = rec + 2 + c;
+    const IdT* rec_h = rec + 2 + 2 * c;
+    const IdT* rec_d = rec_h + nn;
     const int slot_m = cl[0];
     const int head_m = m.tree[slot_m];
     MST_SYNC();
@@ -413,7 +424,7 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
     MST_SYNC();
     for (int i = lane; i < c; i += 64) { m.tree[cl[i]] = tc[i]; m.alive[cl[i]] = 1; }
     MST_SYNC();
-    if (lane == 0) m.tree[cl[rec_h[rank_head]]] = (uint8_t)head_m;
+    if (lane == 0) m.tree[cl[rec_h[rank_head]]] = (IdT)head_m;
     MST_SYNC();
   }
   return true;
@@ -421,7 +432,8 @@ __device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
 
 // S[k][j] for k >= 1 from the probability tensor (utils.py:569-574): crop to n columns, zero diagonal
 // Returns whether the matrix holds a NaN (wave-uniform).
-__device__ inline bool build_scores(const MstLds& m, const float* p, int n, int T, int lane, int root) {
+template <typename IdT>
+__device__ inline bool build_scores(const MstLdsT<IdT>& m, const float* p, int n, int T, int lane, int root) {
   bool nan = false;
   // flattened over (k, j) with 8 independent loads in flight per lane (a row-by-row loop pays one
   // global-load latency per row: ~130 us of a 129-node task)
@@ -463,22 +475,32 @@ struct MstWs {
   int32_t* task_sent;   // [B*L]
   int32_t* task_root;   // [B*L]
   double* task_score;   // [B*L]
-  uint8_t* task_tree;   // [B*L][L+1]
+  void* task_tree;      // [B*L][L+1] node ids (1 or 2 bytes each)
   double* s_first;      // long-sentence mode only: [B][n_max * ld] score matrices of the first pass
-  double* s_root;       // and [MST_GLOBAL_ROOT_BLOCKS][n_max * ld] of the root pass
+  double* s_root;       // and [mst_root_blocks][n_max * ld] of the root pass
+  uint16_t* rec_first;  // 16-bit ids only: [B][rec_cap] contraction records of the first pass
+  uint16_t* rec_root;   // and [mst_root_blocks][rec_cap] of the root pass
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ inline size_t mst_s_elems(int L) { return (size_t)(L + 1) * ((L + 1) | 1); }
+__host__ inline int mst_id_bytes(int L) { return L + 1 > MST_MAX_N_GLOBAL ? 2 : 1; }
 __host__ inline size_t mst_root_blocks(int B, int L) {  // workgroups of the root kernel in workspace mode
   const size_t nt = (size_t)B * L;
-  return nt < (size_t)MST_GLOBAL_ROOT_BLOCKS ? nt : (size_t)MST_GLOBAL_ROOT_BLOCKS;
+  size_t cap = (size_t)MST_GLOBAL_ROOT_BLOCKS;
+  if (mst_id_bytes(L) == 2) {  // a private matrix is up to 34 MB there: as many as the budget holds
+    const size_t fit = MST_LONG_ROOT_BYTES / (8 * mst_s_elems(L) + 2 * mst_rec_cap(L + 1));
+    cap = fit < 8 ? 8 : (fit < cap ? fit : cap);
+  }
+  return nt < cap ? nt : cap;
 }
 __host__ inline size_t mst_ws_bytes(int B, int L) {
   const size_t nt = (size_t)B * L;
-  size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1));
+  const int id = mst_id_bytes(L);
+  size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1) * id);
   if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * (size_t)B;
   if (L + 1 >= MST_ROOT_GLOBAL_N) b += 8 * mst_s_elems(L) * mst_root_blocks(B, L);
+  if (id == 2) b += align16(2 * mst_rec_cap(L + 1)) * ((size_t)B + mst_root_blocks(B, L));
   return b;
 }
 __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
@@ -491,13 +513,22 @@ __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
   w.task_sent = (int32_t*)q; q += align16(4 * nt);
   w.task_root = (int32_t*)q; q += align16(4 * nt);
   w.task_score = (double*)q; q += align16(8 * nt);
-  w.task_tree = (uint8_t*)q; q += align16(nt * (L + 1));
+  w.task_tree = (void*)q; q += align16(nt * (L + 1) * mst_id_bytes(L));
   w.s_first = (double*)q;
   w.s_root = w.s_first + (L + 1 > MST_MAX_N ? mst_s_elems(L) * B : 0);
+  w.rec_first = (uint16_t*)(w.s_root + (L + 1 >= MST_ROOT_GLOBAL_N ? mst_s_elems(L) * mst_root_blocks(B, L) : 0));
+  w.rec_root = w.rec_first + align16(2 * mst_rec_cap(L + 1)) / 2 * (size_t)B;
   return w;
 }
 
-template <bool GS>  // GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words)
+// the per-task slice of the 16-bit contraction records (byte ids keep them in LDS)
+template <typename IdT>
+__device__ __forceinline__ IdT* mst_rec_slice(uint16_t* base, size_t task, int T) {
+  if constexpr (sizeof(IdT) == 2) return base + task * (align16(2 * mst_rec_cap(T)) / 2);
+  else return nullptr;
+}
+
+template <bool GS, typename IdT>  // GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words)
 __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel(const float* __restrict__ probs,
                                                                        const int32_t* __restrict__ lens, int B, int L,
                                                                        int32_t* heads, int32_t* status, MstWs ws,
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
   if (lane == 0) { ws.sent_cnt[b] = 0; ws.sent_base[b] = 0; status[b] = 0; }
   if (len == 0) return;
   const float* p = probs + (size_t)b * L * T;
-  MstLds m = mst_carve(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr);
+  MstLdsT<IdT> m = mst_carve<IdT>(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr, mst_rec_slice<IdT>(ws.rec_first, b, T));
   const bool has_nan = build_scores(m, p, n, T, lane, 0);
   if (!cle_run(m, n, lane, has_nan)) { if (lane == 0) status[b] = 2; return; }
   MST_SYNC();
@@ -582,7 +613,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
   }
 }
 
-template <bool GS>
+template <bool GS, typename IdT>
 __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
                                                                       const int32_t* __restrict__ lens, int B, int L, MstWs ws,
                                                                       int lds_task) {
@@ -598,9 +629,10 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(
     const int root = ws.task_root[t];
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
-    MstLds m = mst_carve(smem, n, GS ? ws.s_root + (size_t)(blockIdx.x * wpb + wave) * T * (T | 1) : nullptr);
+    MstLdsT<IdT> m = mst_carve<IdT>(smem, n, GS ? ws.s_root + (size_t)(blockIdx.x * wpb + wave) * T * (T | 1) : nullptr,
+                                    mst_rec_slice<IdT>(ws.rec_root, blockIdx.x * wpb + wave, T));
     const bool has_nan = build_scores(m, p, n, T, lane, root);
-    uint8_t* tt = ws.task_tree + (size_t)t * T;
+    IdT* tt = reinterpret_cast<IdT*>(ws.task_tree) + (size_t)t * T;
     if (!cle_run(m, n, lane, has_nan)) {
       if (lane == 0) ws.task_score[t] = -INFINITY;
       continue;
@@ -611,7 +643,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(
     bool all_nz = true;
     for (int k = 1 + lane; k < n; k += 64) {
       const int h = m.tree[k];
-      tt[k] = (uint8_t)h;
+      tt[k] = (IdT)h;
       double v;
       if (k == root) v = (h == 0) ? 1.0 : 0.0;
       else if (h == 0 || h == k) v = 0.0;
@@ -628,6 +660,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(
   }
 }
 
+template <typename IdT>
 __global__ __launch_bounds__(64) void mst_select_kernel(const int32_t* __restrict__ lens, int B, int L, int32_t* heads,
                                                         int32_t* status, MstWs ws) {
   const int b = blockIdx.x;
@@ -646,7 +679,7 @@ __global__ __launch_bounds__(64) void mst_select_kernel(const int32_t* __restric
     return;
   }
   const int n = min(max(lens[b], 0), L) + 1;
-  const uint8_t* tt = ws.task_tree + (size_t)bt * (L + 1);
+  const IdT* tt = reinterpret_cast<const IdT*>(ws.task_tree) + (size_t)bt * (L + 1);
   for (int k = 1 + lane; k < n; k += 64) heads[(size_t)b * L + k - 1] = tt[k];
   if (lane == 0) status[b] = 0;
 }
@@ -661,45 +694,53 @@ extern "C" size_t cube_mst_workspace_bytes(int B, int L) {
 namespace {
 
 // Launch sequence shared by cube_mst_decode and cube_mst_decode_noalloc; `workspace` holds mst_ws_bytes(B, L) bytes.
-int mst_decode_impl(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
-                    void* workspace, hipStream_t st) {
-  const bool gs_first = L + 1 > MST_MAX_N, gs_root = L + 1 >= MST_ROOT_GLOBAL_N;
-  const size_t task_first = (mst_lds_bytes(L + 1, gs_first) + 15) & ~(size_t)15, task_root = (mst_lds_bytes(L + 1, gs_root) + 15) & ~(size_t)15;
+// Variants: S in LDS (up to 129 words; the rooted re-runs up to 94) / in the workspace, byte ids; 16-bit ids from 255 words.
+template <bool GS_FIRST, bool GS_ROOT, typename IdT>
+int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status, const MstWs& ws,
+               hipStream_t st) {
+  constexpr int ID = (int)sizeof(IdT);
+  const size_t task_first = (mst_lds_bytes(L + 1, GS_FIRST, ID) + 15) & ~(size_t)15;
+  const size_t task_root = (mst_lds_bytes(L + 1, GS_ROOT, ID) + 15) & ~(size_t)15;
   // tasks per workgroup: as many as the CU's LDS holds (workspace-resident matrices: one, their blocks index the workspace)
   auto waves = [](size_t task, bool gs) {
     if (gs) return 1;
     const size_t w = ((size_t)160 * 1024) / task;
     return (int)(w < 1 ? 1 : (w > (size_t)MST_MAX_WAVES ? (size_t)MST_MAX_WAVES : w));
   };
-  const int w_first = waves(task_first, gs_first), w_root = waves(task_root, gs_root);
+  const int w_first = waves(task_first, GS_FIRST), w_root = waves(task_root, GS_ROOT);
   const size_t lds_first = task_first * w_first, lds_root = task_root * w_root;
-  static CubeLdsReservation reserved[4];
-  const void* fn_first = gs_first ? (const void*)mst_first_kernel<true> : (const void*)mst_first_kernel<false>;
-  const void* fn_root = gs_root ? (const void*)mst_root_kernel<true> : (const void*)mst_root_kernel<false>;
-  if (!reserved[gs_first ? 2 : 0].ensure(fn_first, lds_first) || !reserved[gs_root ? 3 : 1].ensure(fn_root, lds_root))
+  static CubeLdsReservation reserved[2];
+  if (!reserved[0].ensure((const void*)mst_first_kernel<GS_FIRST, IdT>, lds_first) ||
+      !reserved[1].ensure((const void*)mst_root_kernel<GS_ROOT, IdT>, lds_root))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds_first > lds_root ? lds_first : lds_root);
-  MstWs ws = mst_ws_carve(workspace, B, L);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
-  const dim3 g_first((B + w_first - 1) / w_first), b_first(64 * w_first);
-  if (gs_first)
-    hipLaunchKernelGGL(mst_first_kernel<true>, g_first, b_first, lds_first, st, probs, lens, B, L, heads, status, ws, (int)task_first);
-  else
-    hipLaunchKernelGGL(mst_first_kernel<false>, g_first, b_first, lds_first, st, probs, lens, B, L, heads, status, ws, (int)task_first);
+  hipLaunchKernelGGL((mst_first_kernel<GS_FIRST, IdT>), dim3((B + w_first - 1) / w_first), dim3(64 * w_first), lds_first, st, probs,
+                     lens, B, L, heads, status, ws, (int)task_first);
   CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
-  if (gs_root) {
-    hipLaunchKernelGGL(mst_root_kernel<true>, dim3((unsigned)mst_root_blocks(B, L)), dim3(64), lds_root, st, probs, lens, B, L, ws,
-                       (int)task_root);
+  // one task per candidate root, at most B*L of them; the grid strides over the device-side count
+  int nblk;
+  if (GS_ROOT) {
+    nblk = (int)mst_root_blocks(B, L);  // = the private score matrices the workspace holds
   } else {
-    // one task per candidate root, at most B*L of them; the grid strides over the device-side count
-    int nblk = (B * L + w_root - 1) / w_root;
+    nblk = (B * L + w_root - 1) / w_root;
     const int cap = w_root > 1 ? MST_ROOT_MAX_BLOCKS : 4096;
     if (nblk > cap) nblk = cap;
-    hipLaunchKernelGGL(mst_root_kernel<false>, dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws, (int)task_root);
   }
+  hipLaunchKernelGGL((mst_root_kernel<GS_ROOT, IdT>), dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws,
+                     (int)task_root);
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
-  hipLaunchKernelGGL(mst_select_kernel, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
+  hipLaunchKernelGGL(mst_select_kernel<IdT>, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
   CUBE_CHECK_LAUNCH("cube_mst_decode(select)");
   return CUBE_OK;
+}
+
+int mst_decode_impl(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status,
+                    void* workspace, hipStream_t st) {
+  const MstWs ws = mst_ws_carve(workspace, B, L);
+  if (L + 1 > MST_MAX_N_GLOBAL) return mst_launch<true, true, uint16_t>(probs, lens, B, L, heads, status, ws, st);
+  if (L + 1 > MST_MAX_N) return mst_launch<true, true, uint8_t>(probs, lens, B, L, heads, status, ws, st);
+  if (L + 1 >= MST_ROOT_GLOBAL_N) return mst_launch<false, true, uint8_t>(probs, lens, B, L, heads, status, ws, st);
+  return mst_launch<false, false, uint8_t>(probs, lens, B, L, heads, status, ws, st);
 }
 
 }  // namespace
@@ -709,7 +750,7 @@ extern "C" int cube_mst_decode(const float* probs, const int32_t* lens, int B, i
   CUBE_ENTRY();
   if (B <= 0 || L <= 0) return CUBE_OK;
   if (!probs || !lens || !heads || !status || !workspace) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: null pointer");
-  if (L + 1 > MST_MAX_N_GLOBAL) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
+  if (L + 1 > MST_MAX_N_LONG) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: sentences longer than %d words are not supported", MST_MAX_N_LONG - 1);
   if (workspace_bytes < mst_ws_bytes(B, L)) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode: workspace too small (%zu < %zu)", workspace_bytes, mst_ws_bytes(B, L));
   if ((uintptr_t)workspace % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_mst_decode: workspace must be 16-byte aligned");
   return mst_decode_impl(probs, lens, B, L, heads, status, workspace, (hipStream_t)stream);
@@ -754,8 +795,8 @@ extern "C" int cube_mst_decode_noalloc(const float* probs, const int32_t* lens, 
   CUBE_ENTRY();
   if (B <= 0 || L <= 0) return CUBE_OK;
   if (!probs || !lens || !heads || !status) CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: null pointer");
-  if (L + 1 > MST_MAX_N_GLOBAL)
-    CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: sentences longer than %d words are not supported", MST_MAX_N_GLOBAL - 1);
+  if (L + 1 > MST_MAX_N_LONG)
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: sentences longer than %d words are not supported", MST_MAX_N_LONG - 1);
   if (mst_ws_bytes(B, L) > (size_t)CUBE_MST_NOALLOC_BYTES)
     CUBE_FAIL(CUBE_ERR_ARG, "cube_mst_decode_noalloc: B=%d x L=%d needs %zu bytes of scratch, the built-in buffer holds %zu "
               "(use cube_mst_decode with a caller workspace)", B, L, mst_ws_bytes(B, L), (size_t)CUBE_MST_NOALLOC_BYTES);

@@ -289,16 +289,22 @@ class TraceLib:
     def cube_mst_workspace_bytes(B, L):
         a16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
         nt = B * L
-        b = 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * (L + 1))
-        if L + 1 > 130:  # long-sentence mode: score matrices of the first pass in the workspace
-            b += 8 * (L + 1) * ((L + 1) | 1) * B
-        if L + 1 >= 96:  # the rooted re-runs keep theirs there from 96 nodes on (one per workgroup)
-            b += 8 * (L + 1) * ((L + 1) | 1) * min(nt, 1792)
+        n = L + 1
+        idb = 2 if n > 255 else 1  # bytes per node id
+        s_bytes, rec_bytes = 8 * n * (n | 1), a16(2 * (n * n + 3 * n + 16))
+        root_blocks = min(nt, 1792 if idb == 1 else max(8, min(1792, (2 << 30) // (s_bytes + 2 * (n * n + 3 * n + 16)))))
+        b = 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * n * idb)
+        if n > 130:  # long-sentence mode: score matrices of the first pass in the workspace
+            b += s_bytes * B
+        if n >= 96:  # the rooted re-runs keep theirs there from 96 nodes on (one per workgroup)
+            b += s_bytes * root_blocks
+        if idb == 2:  # 16-bit node ids: the contraction records too
+            b += rec_bytes * (B + root_blocks)
         return b
 
     def cube_mst_decode(self, probs, lens, B, L, heads, status, ws, ws_bytes, stream):
         self.calls.append(("mst", B, L))
-        assert L + 1 <= 255 and ws_bytes >= self.cube_mst_workspace_bytes(B, L)
+        assert L + 1 <= 2048 and ws_bytes >= self.cube_mst_workspace_bytes(B, L)
         self._need("mst probs", probs, 4 * B * L * (L + 1), 4)
         self._need("mst lens", lens, 4 * B, 4)
         self._need("mst heads", heads, 4 * B * L, 4)

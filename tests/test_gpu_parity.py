@@ -218,13 +218,14 @@ def test_mst_matches_reference_heads(dev, golden_dir):
 
 
 def test_mst_long_sentences_match_oracle(dev):
-    """Sentences of 130..254 words (score matrix in the workspace instead of LDS) against the NumPy
-    restatement of the reference decoder (itself pinned by G4); 255+ words are refused."""
+    """Sentences of 130..254 words (score matrix in the workspace instead of LDS) and of 255..2047 words (16-bit node
+    ids, contraction records in the workspace too) against the NumPy restatement of the reference decoder (itself
+    pinned by G4); 2048+ words are refused."""
     from oracle import cle_oracle
     from cube_amd.networks.utils import ChuLiuEdmondsDecoder
     dec = ChuLiuEdmondsDecoder(dev)
     rng = np.random.default_rng(17)
-    for L, B, sigma in ((130, 3, 4.0), (200, 2, 6.0), (254, 2, 8.0)):
+    for L, B, sigma in ((130, 3, 4.0), (200, 2, 6.0), (254, 2, 8.0), (255, 2, 8.0), (300, 3, 1.0), (700, 2, 6.0)):
         logits = rng.standard_normal((B, L, L + 1)) * sigma
         e = np.exp(logits - logits.max(-1, keepdims=True))
         probs = (e / e.sum(-1, keepdims=True)).astype(np.float32)
@@ -233,8 +234,13 @@ def test_mst_long_sentences_match_oracle(dev):
         exp = cle_oracle.decode(probs, lens)
         for b in range(B):
             np.testing.assert_array_equal(got[b], exp[b], err_msg="L=%d b=%d" % (L, b))
+    from cube_amd import hip
+    lib = hip.load()
+    assert lib.cube_mst_workspace_bytes(4, 2047) > 0
     with pytest.raises(Exception):
-        dec.decode(np.full((1, 255, 256), 1.0 / 256, dtype=np.float32), np.array([255]))
+        d = torch.zeros(1, device=dev)
+        hip.check(lib.cube_mst_decode(d.data_ptr(), d.data_ptr(), 1, 2048, d.data_ptr(), d.data_ptr(), d.data_ptr(), 1 << 40, None),
+                  "cube_mst_decode")
 
 
 def test_mst_ties_and_zeros_match_oracle(dev):

@@ -210,7 +210,7 @@ def test_abi_rejects_bad_arguments():
     assert "rnn_size" in err(lib.cube_bilstm_recurrent(P, P, None, 4, 5, 300, P, None, 640, 0, None))
     assert "whh_lo" in err(lib.cube_bilstm_recurrent(P, P, P, 4, 5, 200, P, None, 448, 0, None))
     assert "D/columns" in err(lib.cube_biaffine_arc(P, None, 128, P, None, 256, 128, 100, 2, 9, P, P, None))
-    assert "longer than" in err(lib.cube_mst_decode(P, P, 1, 300, P, P, P, 1 << 30, None))
+    assert "longer than" in err(lib.cube_mst_decode(P, P, 1, 2048, P, P, P, 1 << 40, None))
     assert "workspace too small" in err(lib.cube_mst_decode(P, P, 4, 16, P, P, P, 16, None))
     assert lib.cube_mst_workspace_bytes(4, 200) > lib.cube_mst_workspace_bytes(4, 100) > 0
     assert "D/columns" in err(lib.cube_label_score(P, None, 448, 224, 288, P, None, P, 10, P, P, 2, 3, P, P, None))
