@@ -786,6 +786,29 @@ def _check_batch_against_oracle(p, r, e, sl, min_agree=0.999):
     assert nbad == 0 and agree >= 0.999, (nbad, agree)
 
 
+def test_sentence_of_300_words_matches_oracle(dev):
+    """A sentence longer than 254 words (the reference has no length limit): the whole path -- word-level
+    convolutions and BiLSTM over 301 positions, arc soft-max over 301 columns, the decoder with 16-bit node ids --
+    against the fp32 oracle, in a batch with short sentences; `process` writes the same heads into the Document."""
+    from oracle import parser_oracle
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    sl = [300, 5, 41, 1]
+    doc = synth.make_document(enc, sl, seed=77, ext_word_emb=tuple(case["ext"]))
+    col = MorphoCollate(enc)
+    r = p.decode_batch(col.collate_fn(doc.sentences, targets=False))
+    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="fp32")
+    with torch.no_grad():
+        e = ora.decode_batch(parser_oracle.collate(doc.sentences, enc))
+    _check_batch_against_oracle(p, r, e, sl, min_agree=0.98)
+    heads = r["heads"].cpu().numpy().copy()
+    assert _is_single_rooted_tree(heads[0, :300])
+    p.process(doc, col, batch_size=4)
+    assert [int(w.head) for w in doc.sentences[0].words] == heads[0, :300].tolist()
+
+
 def test_config2_full_size(dev):
     """BASELINE configs[2] at full size: exactly the first batch of `bench.py --config 2` (64 sentences x 128
     tokens, default ParserConfig, weights seed 1234).  (1) every tree single-rooted; (2) the MST heads of all 64
