@@ -101,6 +101,9 @@ struct GemmParams {
 // [row0_in, row0_in + n_rows) as sequences of seq_in rows, writes the first seq_out positions of
 // each sequence to rows row0_out + j*seq_out + pos, and its sequences are words word0, word0+1, ...
 typedef cube_conv_groups ConvGroups;
+// per group, computed on the host for the tile shape of the launch: first row tile, output rows per tile, output
+// rows of the group (the kernel's tile -> group search is then a scalar scan without integer divisions)
+struct ConvTiles { int tile0[CUBE_MAX_CONV_GROUPS + 1]; int bm[CUBE_MAX_CONV_GROUPS]; int n_out[CUBE_MAX_CONV_GROUPS]; };
 
 __device__ __forceinline__ void store_bf16(uint16_t* hi, uint16_t* lo, size_t idx, float v) {
   if (lo) {
@@ -136,7 +139,7 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 // passes lda/2 and Kc/2); x = 128*hi + lo, the products hi*hi and hi*lo + lo*hi accumulate exactly
 // in two int32 sets (v_mfma_i32_32x32x32_i8, twice the bf16 rate) and are combined in the epilogue.
 template <int EPI, bool SPLIT, class C, bool I8 = false>
-__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg) {
+__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg, const ConvTiles ct) {
   static_assert(!I8 || (SPLIT && EPI == CUBE_EPI_GATE), "int8x2 is built for the gated convolutions only");
   using acc_t = typename std::conditional<I8, i32x16, f32x16>::type;
   using frag_t = typename std::conditional<I8, i32x4, bf16x8>::type;
@@ -173,14 +176,11 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   int row_lo = 0, seq = p.seq_len, seq_out = p.seq_len, row0_out = 0, word0 = 0;
   int n_out = p.M, ro0 = mt * BM, bm = BM;
   if (cg.n > 0) {
-    int g = 0, t0 = 0;
-    for (;; ++g) {
-      bm = tile_rows(BM, SR, cg.seq_in[g], cg.seq_out[g]);
-      n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
-      const int nt = (n_out + bm - 1) / bm;
-      if (mt < t0 + nt || g == cg.n - 1) break;
-      t0 += nt;
-    }
+    int g = 0;
+    while (g + 1 < cg.n && mt >= ct.tile0[g + 1]) ++g;
+    const int t0 = ct.tile0[g];
+    bm = ct.bm[g];
+    n_out = ct.n_out[g];
     row_lo = cg.row0_in[g]; seq = cg.seq_in[g]; seq_out = cg.seq_out[g];
     row0_out = cg.row0_out[g]; word0 = cg.word0[g];
     ro0 = (mt - t0) * bm;
@@ -193,32 +193,6 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   const int nkc = p.Kc / BK;
   const int nk = nkc * taps;
   const int ktot = taps * p.Kc;
-
-  if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
-  // per tile row, computed once (one division per row): which taps fall inside the row's sequence,
-  // where its output goes (-1: nowhere), which slab row it reads and the offset of its bias vector
-  // in bias_tab.  Read after the first barrier below.
-  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB, OROW_OFF = ROWOFF_OFF + BM * 4, MASK_OFF = OROW_OFF + BM * 4,
-                AROW_OFF = MASK_OFF + BM * 4;
-  if (tid < BM) {
-    const int ro = ro0 + tid;
-    unsigned off = 0, m = 0;
-    int orow = -1, arow = 0;
-    if (tid < bm && ro < n_out) {
-      const int j = ro / seq_out, pos = ro - j * seq_out;
-      for (int t = 0; t < taps; ++t) {
-        const int pp = pos + t - half_taps;
-        if (pp >= 0 && pp < seq) m |= 1u << t;
-      }
-      orow = row0_out + ro;
-      arow = row_lo + j * seq + pos - in0;
-      if (p.bias_tab) off = ((unsigned)p.row_group[cg.n > 0 ? word0 + j : ro] * 32u + m) * (unsigned)p.N;
-    }
-    reinterpret_cast<uint32_t*>(smem + ROWOFF_OFF)[tid] = off;
-    reinterpret_cast<int32_t*>(smem + OROW_OFF)[tid] = orow;
-    reinterpret_cast<uint32_t*>(smem + MASK_OFF)[tid] = m;
-    reinterpret_cast<int32_t*>(smem + AROW_OFF)[tid] = arow;
-  }
 
   // ---- DMA source offsets (elements) of this lane for the pieces its wave issues
   size_t a_src[PA], b_src[PB];
@@ -283,6 +257,32 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   if constexpr (NB >= 3) {
     if (nk > 1) ISSUE_B(1, 1)
   }
+  if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;
+  // (after the first DMAs are out: their flight covers this)  per tile row, computed once (one division per row): which taps fall inside the row's sequence,
+  // where its output goes (-1: nowhere), which slab row it reads and the offset of its bias vector
+  // in bias_tab.  Read after the first barrier below.
+  constexpr int ROWOFF_OFF = ZERO_OFF + ROWB, OROW_OFF = ROWOFF_OFF + BM * 4, MASK_OFF = OROW_OFF + BM * 4,
+                AROW_OFF = MASK_OFF + BM * 4;
+  if (tid < BM) {
+    const int ro = ro0 + tid;
+    unsigned off = 0, m = 0;
+    int orow = -1, arow = 0;
+    if (tid < bm && ro < n_out) {
+      const int j = ro / seq_out, pos = ro - j * seq_out;
+      for (int t = 0; t < taps; ++t) {
+        const int pp = pos + t - half_taps;
+        if (pp >= 0 && pp < seq) m |= 1u << t;
+      }
+      orow = row0_out + ro;
+      arow = row_lo + j * seq + pos - in0;
+      if (p.bias_tab) off = ((unsigned)p.row_group[cg.n > 0 ? word0 + j : ro] * 32u + m) * (unsigned)p.N;
+    }
+    reinterpret_cast<uint32_t*>(smem + ROWOFF_OFF)[tid] = off;
+    reinterpret_cast<int32_t*>(smem + OROW_OFF)[tid] = orow;
+    reinterpret_cast<uint32_t*>(smem + MASK_OFF)[tid] = m;
+    reinterpret_cast<int32_t*>(smem + AROW_OFF)[tid] = arow;
+  }
+
   __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -354,9 +354,11 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (I8) {
-          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][1], fb[ks][0][j], acc2[i][j], 0, 0, 0);
-          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][1][j], acc2[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][0][j], acc[i][j], 0, 0, 0);
+          // weights as the A operand: the accumulators hold the TRANSPOSED tile (lane = activation row, registers =
+          // channels in runs of four), which the epilogue packs into dwords without crossing lanes
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][0][j], fa[u % AR][1], acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][1][j], fa[u % AR][0], acc2[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][0][j], fa[u % AR][0], acc[i][j], 0, 0, 0);
         } else {
           if constexpr (SPLIT) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u % AR][1], fb[ks][0][j], acc[i][j], 0, 0, 0);
@@ -431,39 +433,50 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     if constexpr (I8) {
       // int8x2 planes out: pre-activation = (128*hh + cross) * w_scale[col] + bias, the gate value g in
       // (-1, 1) as q = round(g * CUBE_I8_ONE) = 128*hi + lo with hi in [-127, 127], lo in [-64, 63].
-      // 32x32 tiles transposed through wave-private LDS, 16 bytes (16 channels) per lane and plane.
+      // Transposed accumulators (see the MFMA calls): this lane owns activation row i*32 + l31 and, of the
+      // wave's 32 channels, c = 8*g + 4*lh + e for register r = 4*g + e -- four consecutive channels per g,
+      // i.e. one dword of each int8 plane.  The dwords go through wave-private LDS rows (32 bytes per
+      // activation row and plane) so that the global stores are 16 bytes per lane.
       constexpr int SROW8 = 48;
       unsigned char* stg = smem + wid * (2 * 32 * SROW8);
       unsigned char* out8 = reinterpret_cast<unsigned char*>(p.out0);
       unsigned char* out8_lo = reinterpret_cast<unsigned char*>(p.out0_lo);
-      const float ws_a = p.w_scale[wcol0 + l31], ws_b = p.w_scale[wcol0 + 32 + l31];
+      float4 ws_a[4], ws_b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ws_a[g] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 8 * g + 4 * lh);
+        ws_b[g] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 32 + 8 * g + 4 * lh);
+      }
       const int srow = lane >> 1, schunk = lane & 1;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        float ba[16], bb[16];
+        const int lrow = wrow0 - m0 + i * 32 + l31;  // row inside the block tile
+        const float* bsrc = btab ? btab + (size_t)rowoff[lrow] + wcol0 : p.bias + wcol0;
+        float4 ba[4], bb[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (btab) {
-            const size_t o = tab_off(row);
-            ba[r] = btab[o];
-            bb[r] = btab[o + 32];
-          } else {
-            ba[r] = bias_a;
-            bb[r] = bias_b;
-          }
+        for (int g = 0; g < 4; ++g) {
+          ba[g] = *reinterpret_cast<const float4*>(bsrc + 8 * g + 4 * lh);
+          bb[g] = *reinterpret_cast<const float4*>(bsrc + 32 + 8 * g + 4 * lh);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const float ca = fmaf((float)acc[i][0][r], 128.f, (float)acc2[i][0][r]) * ws_a + ba[r];
-          const float cb = fmaf((float)acc[i][1][r], 128.f, (float)acc2[i][1][r]) * ws_b + bb[r];
-          const float g = tanhf_(ca) * sigmoidf_(cb);
-          int q = __float2int_rn(g * (float)CUBE_I8_ONE);
-          q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-          const int h = (q + 64) >> 7;
-          stg[lr * SROW8 + l31] = (unsigned char)h;
-          stg[32 * SROW8 + lr * SROW8 + l31] = (unsigned char)(q - (h << 7));
+        for (int g = 0; g < 4; ++g) {
+          const float wa[4] = {ws_a[g].x, ws_a[g].y, ws_a[g].z, ws_a[g].w}, wb[4] = {ws_b[g].x, ws_b[g].y, ws_b[g].z, ws_b[g].w};
+          const float xa[4] = {ba[g].x, ba[g].y, ba[g].z, ba[g].w}, xb[4] = {bb[g].x, bb[g].y, bb[g].z, bb[g].w};
+          uint32_t dh = 0, dl = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float ca = fmaf((float)acc[i][0][r], 128.f, (float)acc2[i][0][r]) * wa[e] + xa[e];
+            const float cb = fmaf((float)acc[i][1][r], 128.f, (float)acc2[i][1][r]) * wb[e] + xb[e];
+            const float gv = tanhf_(ca) * sigmoidf_(cb);
+            int q = __float2int_rn(gv * (float)CUBE_I8_ONE);
+            q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
+            const int h = (q + 64) >> 7;
+            dh |= (uint32_t)(h & 255) << (8 * e);
+            dl |= (uint32_t)((q - (h << 7)) & 255) << (8 * e);
+          }
+          *reinterpret_cast<uint32_t*>(stg + l31 * SROW8 + 8 * g + 4 * lh) = dh;
+          *reinterpret_cast<uint32_t*>(stg + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -593,16 +606,18 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   }
 }
 
-// row tiles of a launch with tile height BM / slab SR (-1: a sequence does not fit the slab)
-inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR) {
+// row tiles of a launch with tile height BM / slab SR (-1: a sequence does not fit the slab); `ct`: the per-group table
+inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR, ConvTiles* ct = nullptr) {
   if (cg.n <= 0) return (M + BM - 1) / BM;
   int tiles = 0;
   for (int g = 0; g < cg.n; ++g) {
     const int bm = tile_rows(BM, SR, cg.seq_in[g], cg.seq_out[g]);
     if (bm < 1) return -1;
     const int n_out = cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+    if (ct) { ct->tile0[g] = tiles; ct->bm[g] = bm; ct->n_out[g] = n_out; }
     tiles += (n_out + bm - 1) / bm;
   }
+  if (ct) ct->tile0[cg.n] = tiles;
   return tiles;
 }
 
@@ -615,10 +630,11 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C, I8>, lds))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
   p.n_tiles = p.N / C::BN;
-  p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR);
+  ConvTiles ct = {};
+  p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR, &ct);
   if (p.m_tiles < 0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: a sequence group does not fit the activation slab");
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
-  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg, ct);
   return CUBE_OK;
 }
 
@@ -743,6 +759,8 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       if (i8) {
         if (half % 16 || a->ldo0 % 16 || a->col0 % 16 || !aligned16(a->out0) || !aligned16(a->out0_lo))
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: out0 planes need 16-byte aligned rows (half, ldo0, col0 multiples of 16)");
+        if (!aligned16(w_scale) || !aligned16(a->bias) || !aligned16(a->bias_tab))
+          CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: w_scale, bias and bias_tab must be 16-byte aligned (read four floats at a time)");
         rc = launch_cfg<CUBE_EPI_GATE, true, CfgI8, true>(p, cg, st);
         break;
       }
@@ -759,10 +777,12 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
 
 }  // namespace
 
-extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) { return gemm_entry(a, nullptr, stream); }
+extern "C" int cube_gemm_bf16(const cube_gemm_args* a, void* stream) {
+  CUBE_ENTRY();
+  return gemm_entry(a, nullptr, stream);
+}
 
 extern "C" int cube_gemm_i8x2(const cube_gemm_args* a, const float* w_scale, void* stream) {
-  CUBE_ENTRY();
   CUBE_ENTRY();
   if (!w_scale) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: null w_scale");
   return gemm_entry(a, w_scale, stream);

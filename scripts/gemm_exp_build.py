@@ -1,0 +1,71 @@
+"""Builds ab_tmp/lib_<name>.so: the whole library with an experiment variant of csrc/gemm.hip's int8x2 tile
+(timing experiments only: results are wrong by construction).  python scripts/gemm_exp_build.py NOMFMA|NOFRAG|NODMA|NOEPI|BASE"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nlp-cube_amd/csrc")
+name = sys.argv[1]
+s = open(os.path.join(CSRC, "gemm.hip")).read()
+
+
+def rep(old, new, count=1):
+    global s
+    assert s.count(old) >= 1, old
+    s = s.replace(old, new, count)
+
+
+if name == "NOMFMA":
+    rep('''          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][1], fb[ks][0][j], acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][1][j], acc2[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u % AR][0], fb[ks][0][j], acc[i][j], 0, 0, 0);''',
+        '''          asm volatile("" ::"v"(fa[u % AR][1]), "v"(fa[u % AR][0]), "v"(fb[ks][0][j]), "v"(fb[ks][1][j]));''')
+elif name == "NOFRAG":
+    s = s.replace("*reinterpret_cast<const frag_t*>(", "opaque_frag<frag_t>(")
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", '''template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__''')
+elif name == "NODMA":
+    rep('''  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);''', '''  asm volatile("" ::"v"(g), "v"(l));''')
+elif name == "NOEPI":
+    rep('''    if constexpr (I8) {
+      // int8x2 planes out:''', '''    if constexpr (I8) {
+      int sum_ = 0;
+      for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum_ += acc[i][j][r] ^ acc2[i][j][r];
+      if (sum_ == 0x12345678) reinterpret_cast<int*>(p.out0)[0] = sum_;
+      return;
+      // int8x2 planes out:''')
+elif name == "EPI_NOBTAB":  # (the first `if (btab)` block of the kernel is the int8x2 epilogue's)
+    rep("          if (btab) {\n            const size_t o = tab_off(row);", "          if (false) {\n            const size_t o = tab_off(row);")
+elif name == "EPI_NOTRANS":
+    rep("          const float g = tanhf_(ca) * sigmoidf_(cb);\n          int q =", "          const float g = ca * cb;\n          int q =")
+elif name == "EPI_NOSTORE":
+    rep("        if (row >= 0 && cbase < p.n_valid) {\n          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes",
+        "        if (row == -12345 && cbase < p.n_valid) {\n          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes")
+elif name == "PROF":  # wall-clock stamps (10 ns units) per workgroup of the int8x2 tile: entry, prologue done, loop done, end
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """__device__ long long g_gemm_prof[4 * 4096];
+template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+    rep("  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  constexpr int BM = C::BM, BN = C::BN;",
+        "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  const long long t0_ = wall_clock64();\n  constexpr int BM = C::BM, BN = C::BN;")
+    rep("  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables",
+        "  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables\n  const long long t1_ = wall_clock64();")
+    rep("  // ---- epilogue.  C/D map of 32x32x16:", "  const long long t2_ = wall_clock64();\n  // ---- epilogue.  C/D map of 32x32x16:")
+    rep("        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n      }\n      return;",
+        "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n      }\n"
+        "      if (I8 && tid == 0 && blockIdx.x < 4096) { long long* q_ = g_gemm_prof + 4 * blockIdx.x; q_[0] = t0_; q_[1] = t1_; q_[2] = t2_; q_[3] = wall_clock64(); }\n      return;")
+    s += """
+extern "C" int cube_gemm_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 4 * 4096) == hipSuccess ? 0 : 1; }
+"""
+elif name != "BASE":
+    raise SystemExit("unknown variant")
+os.makedirs(os.path.join(ROOT, "ab_tmp"), exist_ok=True)
+src = os.path.join(ROOT, "ab_tmp/gemm_%s.hip" % name)
+open(src, "w").write(s.replace('#include "common.h"', '#include "../nlp-cube_amd/csrc/common.h"').replace(
+    '#include "../../include/cube_hip.h"', '#include "../include/cube_hip.h"'))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+others = [os.path.join(CSRC, f) for f in g.SOURCES if f != "gemm.hip"]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o",
+                       os.path.join(ROOT, "ab_tmp/lib_%s.so" % name), src] + others)
+print("built", name)
