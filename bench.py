@@ -87,11 +87,12 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300
     return p, cfg, enc, sd, batches, docs
 
 
-def run_steps(p, batches, n):
+def run_steps(p, batches, n, serial=False):
     """n steps, each: device-resident batch -> five int32 arrays on the host (`Parser.submit` /
-    `collect`: the latency-bound second phase of a step overlaps the first phase of the next)."""
+    `collect`: the latency-bound second phase of a step overlaps the first phase of the next).
+    serial (or CUBE_BENCH_SERIAL=1, the profiling aid): the same steps on ONE stream, kernels never overlap."""
     out = None
-    if os.environ.get("CUBE_BENCH_SERIAL") == "1":  # profiling aid: one stream, kernels never overlap
+    if serial or os.environ.get("CUBE_BENCH_SERIAL") == "1":
         for i in range(n):
             r = p.decode_batch_prepared(batches[i % len(batches)])
             out = r["packed"].cpu()
@@ -254,6 +255,18 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         kt = p.stop_kernel_timing()
+    # kernel-timing pass for the roofline: the same steps on ONE stream, so that the HIP events around a launch
+    # bracket the kernel alone (in the pipelined region above they also bracket the time the launch waits for CUs
+    # held by the other stages' kernels, and the kernel shares the chip with them while it runs)
+    kt_alone = None
+    if rank == 0 and args.config != 3:
+        n_alone = max(1, min(args.steps, 20))
+        run_steps(p, batches, 2, serial=True)
+        torch.cuda.synchronize()
+        p.start_kernel_timing("char_conv")
+        run_steps(p, batches, n_alone, serial=True)
+        torch.cuda.synchronize()
+        kt_alone = p.stop_kernel_timing()
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -282,10 +295,13 @@ def main():
     i8 = "xc_q1" in p._buf._b
     peak = I8_DENSE_PEAK_TOPS if i8 else BF16_DENSE_PEAK_TFLOPS
     flops_executed = 2.0 * rows_exec * 5 * lay.char_half * nf * passes
-    ms = kt["ms_mean"]
+    ms_pipelined = kt["ms_mean"]
+    if kt_alone is None or not kt_alone["ms_mean"]:
+        kt_alone = kt
+    ms = kt_alone["ms_mean"]
     achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms else 0.0
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r1_traffic_i8.json" if i8 else "r1_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "r2_traffic_i8.json" if i8 else "r1_traffic.json")
     if args.config == 1 and world == 1 and os.path.exists(tf):  # PMC pass of this workload, see the file
         with open(tf) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
@@ -298,11 +314,18 @@ def main():
                     peak_is="dense int8 MFMA (2x bf16)" if i8 else "dense bf16 MFMA",
                     frac_of_bf16_peak=achieved / BF16_DENSE_PEAK_TFLOPS,
                     kernel="gemm_kernel<GATE%s> (char conv, layers>=1)" % (", CfgI8, int8x2" if i8 else ""),
-                    launches=kt["n"], ms_per_launch=ms,
+                    launches=kt_alone["n"], ms_per_launch=ms,
+                    measured="HIP events around every launch of the kernel, on its stream, in a pass of the same steps on ONE "
+                             "stream inside this run (rocprofv3 --kernel-trace of CUBE_BENCH_SERIAL=1 bench.py: profiles/*_serial_*)",
+                    pipelined=dict(ms_per_launch=ms_pipelined, launches=kt["n"],
+                                   achieved=flops_per_launch / (ms_pipelined * 1e-3) / 1e12 if ms_pipelined else 0.0,
+                                   frac=flops_per_launch / (ms_pipelined * 1e-3) / 1e12 / peak if ms_pipelined else 0.0,
+                                   note="the same events inside the timed (three-stream) region: they also bracket the wait "
+                                        "for CUs held by the other stages' kernels, which then share the chip with the launch"),
                     flops_per_launch=flops_per_launch, padded_W=bt["W"], rows_algorithmic=NW, rows_executed=rows_exec,
                     mfma_flops_executed_per_launch=flops_executed,
                     mfma_executed_tflops=flops_executed / (ms * 1e-3) / 1e12 if ms else 0.0,
-                    note="launches timed while the other pipeline streams run beside them")
+                    )
     out = {
         "metric": "sentences/sec (node) parser+tagger inference", "value": sent_per_s, "unit": "sentences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

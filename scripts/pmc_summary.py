@@ -31,7 +31,7 @@ out = {
                   "doubled; WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",
     "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `bench.py --steps 5 --warmup 2` "
-           "(scripts/pmc_traffic.sh), mean over the launches of char layers 1-4",
+           "(scripts/pmc_pass.sh, serial run), mean over the launches of char layers 1-4",
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
