@@ -154,7 +154,8 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
  * in 64-channel chunks (W[n, (kc*taps + tap)*64 + c64]), Kc % 64 == 0, lda % 16 == 0, lda / Kc / ldo0 /
  * col0 counted in int8 elements; CUBE_EPI_GATE only, no res / out1 / out2 / rowmap; out0, out0_lo int8
  * planes of the gate values (n_valid, ldo0, col0 multiples of 16).  w_scale f32 [N] in packed column
- * order.  bias / bias_tab / row_group / groups as for cube_gemm_bf16.
+ * order.  bias / bias_tab / row_group / groups as for cube_gemm_bf16; w_scale, bias and bias_tab 16-byte
+ * aligned (the epilogue reads four floats at a time).
  * cube_char_conv0_lookup_i8 / cube_masked_mean_i8: the bf16 entry points with int8x2 planes as the
  * gate-value output / as the layer inputs (ld_out resp. ld_x in int8 elements, multiples of 16 resp. C % 16 == 0). */
 #define CUBE_I8_ONE 16256 /* 127 * 128 */
@@ -213,8 +214,11 @@ int cube_biaffine_arc(const void* u, const void* u_lo, int ld_u, const void* h2,
                       int col_h2, int D, int B, int T, float* logits, float* probs, void* stream);
 
 /* Chu-Liu-Edmonds single-root decoding.  probs f32 [B, L, L+1], lens int32 [B] ->
- * heads int32 [B, L] (0 at pads), status int32 [B] (0 ok, 1 = no tree: the reference asserts).
- * workspace: cube_mst_workspace_bytes(B, L) bytes.                                          */
+ * heads int32 [B, L] (0 at pads), status int32 [B] (0 ok, 1 = no tree: the reference asserts,
+ * 2 = the scores are not probabilities (NaN / negative entries made a contraction that does not
+ * shrink the graph): the kernel stops instead of looping).  L <= 2047 (the reference has no limit;
+ * up to 129 words the score matrix of a task lives in LDS, beyond in the workspace, from 255 words
+ * with 16-bit node ids).  workspace: cube_mst_workspace_bytes(B, L) bytes, 16-byte aligned.     */
 size_t cube_mst_workspace_bytes(int B, int L);
 int cube_mst_decode(const float* probs, const int32_t* lens, int B, int L,
                     int32_t* heads, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
