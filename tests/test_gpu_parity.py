@@ -243,6 +243,35 @@ def test_mst_long_sentences_match_oracle(dev):
                   "cube_mst_decode")
 
 
+def test_mst_terminates_on_scores_that_are_not_probabilities(dev):
+    """Negative, NaN and infinite "probabilities" (a caller's bug, an overwritten buffer): the contraction loop is the
+    one data-dependent loop of the path, and it must end with a status for every sentence instead of spinning on a
+    contraction that does not shrink the graph; the next, valid call decodes as usual."""
+    from oracle import cle_oracle
+    from cube_amd.networks.utils import ChuLiuEdmondsDecoder
+    dec = ChuLiuEdmondsDecoder(dev)
+    rng = np.random.default_rng(31)
+    for L, B in ((7, 32), (40, 16), (128, 4), (150, 2)):
+        g = rng.standard_normal((B, L, L + 1)).astype(np.float32) * 3     # half of the entries negative
+        g[rng.random(g.shape) < 0.02] = np.nan
+        g[rng.random(g.shape) < 0.01] = np.inf
+        g[rng.random(g.shape) < 0.01] = -np.inf
+        lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+        heads, status = dec.decode_device(torch.from_numpy(g).to(dev), lens)
+        torch.cuda.synchronize()
+        assert set(np.unique(status.cpu().numpy()).tolist()) <= {0, 1, 2}
+    probs = _softmax_np(rng.standard_normal((4, 12, 13)))
+    got = dec.decode(probs, np.full(4, 12))
+    exp = cle_oracle.decode(probs, np.full(4, 12))
+    for b in range(4):
+        np.testing.assert_array_equal(got[b], exp[b])
+
+
+def _softmax_np(x):
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
 def test_mst_ties_and_zeros_match_oracle(dev):
     """Quantised probabilities (many exactly equal entries: every first-maximum tie-break counts, and the kernel's
     per-row tie flags decide which rows are scanned again after a contraction) and rows with exact zeros (0/0 = NaN
