@@ -12,9 +12,10 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 
 
-rep('__device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {', '''__device__ long long g_prof[16];
+rep('template <typename IdT>\n__device__ bool cle_run(const MstLdsT<IdT>& m, int n, int lane, bool has_nan) {', '''__device__ long long g_prof[16];
 #define PT(i) { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; }
-__device__ bool cle_run(const MstLds& m, int n, int lane, bool has_nan) {
+template <typename IdT>
+__device__ bool cle_run(const MstLdsT<IdT>& m, int n, int lane, bool has_nan) {
   long long prof[10] = {0,0,0,0,0,0,0,0,0,0}; long long tlast = clock64(); long long tstart = tlast;''')
 rep('''    MST_SYNC();
     // ---- 2. cycles by pointer doubling''', '''    MST_SYNC(); PT(0)
@@ -25,8 +26,8 @@ rep('''    chosen = wave_max_i(chosen);
 rep('''    MST_SYNC();
     // ---- 4. product of the cycle's arc scores, in cycle order''', '''    MST_SYNC(); PT(2)
     // ---- 4. product of the cycle's arc scores, in cycle order''')
-rep('''    uint8_t* rec_d = rec_h + nn;
-    bool new_nan = false;''', '''    uint8_t* rec_d = rec_h + nn; PT(3)
+rep('''    IdT* rec_d = rec_h + nn;
+    bool new_nan = false;''', '''    IdT* rec_d = rec_h + nn; PT(3)
     bool new_nan = false;''')
 rep('''    MST_SYNC();
     // ---- 6. contracted node takes the slot''', '''    MST_SYNC(); PT(4)
