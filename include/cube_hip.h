@@ -109,6 +109,8 @@ typedef struct cube_gemm_args {
   void* out2; void* out2_lo; int ldo2; int col2;
   const float* bias_tab; const int32_t* row_group; int n_groups;
   const cube_conv_groups* groups;   /* optional, host memory */
+  int out0_int8;             /* cube_gemm_bf16, gate epilogue with res: out0 / out0_lo are int8x2 planes of the gate value
+                                (ldo0, col0 in bytes) for a next layer that runs in cube_gemm_i8x2 */
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 
@@ -152,8 +154,10 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
  *   C[r, n] = (128*HH + CROSS) * w_scale[n] + bias,    w_scale[n] = 128 * wmax[n] / CUBE_I8_ONE^2.
  * cube_gemm_i8x2: cube_gemm_args as above with A, A_lo int8 [M, lda], W, W_lo int8 [N, taps*Kc] laid out
  * in 64-channel chunks (W[n, (kc*taps + tap)*64 + c64]), Kc % 64 == 0, lda % 16 == 0, lda / Kc / ldo0 /
- * col0 counted in int8 elements; CUBE_EPI_GATE only, no res / out1 / out2 / rowmap; out0, out0_lo int8
- * planes of the gate values (n_valid, ldo0, col0 multiples of 16).  w_scale f32 [N] in packed column
+ * col0 counted in int8 elements; CUBE_EPI_GATE only, no rowmap; out0, out0_lo int8 planes of the gate
+ * values (n_valid, ldo0, col0 multiples of 16; may both be NULL when res is given).  res (fp32 residual
+ * stream, res_mode 0: res = g, 1: res += g) and the bf16 x + res side outputs out1 / out2 as for
+ * cube_gemm_bf16 (the word-level stack; ld_res, ldo1/2, col1/2 multiples of 4, without sequence groups).  w_scale f32 [N] in packed column
  * order.  bias / bias_tab / row_group / groups as for cube_gemm_bf16; w_scale, bias and bias_tab 16-byte
  * aligned (the epilogue reads four floats at a time).
  * cube_char_conv0_lookup_i8 / cube_masked_mean_i8: the bf16 entry points with int8x2 planes as the

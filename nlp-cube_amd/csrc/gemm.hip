@@ -94,6 +94,7 @@ struct GemmParams {
   uint16_t* out2; uint16_t* out2_lo; int ldo2; int col2;
   int m_tiles; int n_tiles;  // set by launch_cfg
   int vec_out;               // gate epilogue without residual: 16-byte row-contiguous stores are legal
+  int out0_i8;               // bf16 operands, gate epilogue with residual: out0 = int8x2 planes of the gate value (ldo0, col0 in bytes)
   const float* bias_tab; const int32_t* row_group;  // row-dependent bias (broadcast channels folded in)
   const float* w_scale;      // int8x2 only: per packed column, value of one unit of 128*hh + (hl + lh)
 };
@@ -449,9 +450,11 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         ws_b[g] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 32 + 8 * g + 4 * lh);
       }
       const int srow = lane >> 1, schunk = lane & 1;
+      const int chb = wcol0 / 2;  // first of the wave's 32 channels
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int lrow = wrow0 - m0 + i * 32 + l31;  // row inside the block tile
+        const int orow_l = orow_lds[lrow];           // this lane's output row (-1: none)
         const float* bsrc = btab ? btab + (size_t)rowoff[lrow] + wcol0 : p.bias + wcol0;
         float4 ba[4], bb[4];
 #pragma unroll
@@ -464,12 +467,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
           const float wa[4] = {ws_a[g].x, ws_a[g].y, ws_a[g].z, ws_a[g].w}, wb[4] = {ws_b[g].x, ws_b[g].y, ws_b[g].z, ws_b[g].w};
           const float xa[4] = {ba[g].x, ba[g].y, ba[g].z, ba[g].w}, xb[4] = {bb[g].x, bb[g].y, bb[g].z, bb[g].w};
           uint32_t dh = 0, dl = 0;
+          float gq[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             const float ca = fmaf((float)acc[i][0][r], 128.f, (float)acc2[i][0][r]) * wa[e] + xa[e];
             const float cb = fmaf((float)acc[i][1][r], 128.f, (float)acc2[i][1][r]) * wb[e] + xb[e];
             const float gv = tanhf_(ca) * sigmoidf_(cb);
+            gq[e] = gv;
             int q = __float2int_rn(gv * (float)CUBE_I8_ONE);
             q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
             const int h = (q + 64) >> 7;
@@ -478,18 +483,47 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
           }
           *reinterpret_cast<uint32_t*>(stg + l31 * SROW8 + 8 * g + 4 * lh) = dh;
           *reinterpret_cast<uint32_t*>(stg + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
+          if (res) {  // word-level stack: fp32 residual stream (res_mode 0: = g, 1: += g) and the x + res side outputs
+            const int c0 = chb + 8 * g + 4 * lh;  // four consecutive channels of this lane's row
+            if (orow_l >= 0 && c0 < p.n_valid) {
+              float* rp = res + (size_t)orow_l * p.ld_res + c0;
+              float4 rs = res_mode == 0 ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(rp);
+              rs.x += gq[0]; rs.y += gq[1]; rs.z += gq[2]; rs.w += gq[3];
+              *reinterpret_cast<float4*>(rp) = rs;
+              if (p.out1 || p.out2) {
+                const float xs[4] = {rs.x + gq[0], rs.y + gq[1], rs.z + gq[2], rs.w + gq[3]};
+                uint16_t h4[4], l4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_bf16(xs[e], h4[e], l4[e]);
+                const uint2 ph = {(uint32_t)h4[0] | ((uint32_t)h4[1] << 16), (uint32_t)h4[2] | ((uint32_t)h4[3] << 16)};
+                const uint2 pl = {(uint32_t)l4[0] | ((uint32_t)l4[1] << 16), (uint32_t)l4[2] | ((uint32_t)l4[3] << 16)};
+                if (p.out1) {
+                  const size_t o = (size_t)orow_l * p.ldo1 + p.col1 + c0;
+                  *reinterpret_cast<uint2*>(p.out1 + o) = ph;
+                  if (p.out1_lo) *reinterpret_cast<uint2*>(p.out1_lo + o) = pl;
+                }
+                if (p.out2) {
+                  const size_t o = (size_t)orow_l * p.ldo2 + p.col2 + c0;
+                  *reinterpret_cast<uint2*>(p.out2 + o) = ph;
+                  if (p.out2_lo) *reinterpret_cast<uint2*>(p.out2_lo + o) = pl;
+                }
+              }
+            }
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int cbase = wcol0 / 2 + schunk * 16;
-        const int row = orow_lds[wrow0 - m0 + i * 32 + srow];  // -1 = none
-        if (row >= 0 && cbase < p.n_valid) {
-          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes
-          *reinterpret_cast<uint4*>(out8 + o) = *reinterpret_cast<const uint4*>(stg + srow * SROW8 + schunk * 16);
-          *reinterpret_cast<uint4*>(out8_lo + o) = *reinterpret_cast<const uint4*>(stg + 32 * SROW8 + srow * SROW8 + schunk * 16);
+        if (out8) {  // (uniform) int8x2 planes of the gate values for the next layer
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int cbase = wcol0 / 2 + schunk * 16;
+          const int row = orow_lds[wrow0 - m0 + i * 32 + srow];  // -1 = none
+          if (row >= 0 && cbase < p.n_valid) {
+            const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes
+            *reinterpret_cast<uint4*>(out8 + o) = *reinterpret_cast<const uint4*>(stg + srow * SROW8 + schunk * 16);
+            *reinterpret_cast<uint4*>(out8_lo + o) = *reinterpret_cast<const uint4*>(stg + 32 * SROW8 + srow * SROW8 + schunk * 16);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
       return;
     } else if (p.vec_out) {
@@ -565,7 +599,18 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         const int row = orow_lds[wrow0 - m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
         if (row >= 0 && ch_ok) {
           const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
-          if (out0 && res_mode != 3) store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
+          if (out0 && res_mode != 3) {
+            if (p.out0_i8) {  // the next layer reads int8x2 planes (cube_gemm_i8x2): q = round(g * CUBE_I8_ONE) = 128*hi + lo
+              int q = __float2int_rn(g * (float)CUBE_I8_ONE);
+              q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
+              const int h = (q + 64) >> 7;
+              const size_t o = (size_t)row * p.ldo0 + p.col0 + ch;
+              reinterpret_cast<signed char*>(out0)[o] = (signed char)h;
+              reinterpret_cast<signed char*>(out0_lo)[o] = (signed char)(q - (h << 7));
+            } else {
+              store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
+            }
+          }
           if (!res) continue;  // plain gated layer: no residual stream
           const float rs = rv[r] + (res_mode == 2 ? 2.0f * g : g);
           res[(size_t)row * p.ld_res + ch] = rs;
@@ -688,8 +733,16 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   if (a->Kc <= 0 || a->Kc % BKC) CUBE_FAIL(CUBE_ERR_ARG, "%s: Kc=%d not a multiple of %d", fn, a->Kc, BKC);
   if (a->N <= 0 || a->N % 128) CUBE_FAIL(CUBE_ERR_ARG, "%s: N=%d not a multiple of 128", fn, a->N);
   if (a->lda < a->Kc || a->lda % (i8 ? 16 : 8)) CUBE_FAIL(CUBE_ERR_ALIGN, "%s: lda=%d (Kc=%d)", fn, a->lda, a->Kc);
-  if (i8 && (a->epilogue != CUBE_EPI_GATE || !a->A_lo || !a->W_lo || a->res || a->out1 || a->out2 || !a->out0 || !a->out0_lo))
-    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: int8x2 needs both planes of A, W and out0, the gate epilogue and no residual stream");
+  if (i8 && (a->epilogue != CUBE_EPI_GATE || !a->A_lo || !a->W_lo || (a->out0 == nullptr) != (a->out0_lo == nullptr) || a->out0_int8))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: int8x2 needs both planes of A and W (and of out0, if given) and the gate epilogue");
+  if (i8 && a->res) {
+    if (a->res_mode != 0 && a->res_mode != 1) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: res_mode=%d (0 or 1)", a->res_mode);
+    if (a->ld_res % 4 || !aligned16(a->res) || a->ldo1 % 4 || a->col1 % 4 || a->ldo2 % 4 || a->col2 % 4 ||
+        ((uintptr_t)a->out1 | (uintptr_t)a->out1_lo | (uintptr_t)a->out2 | (uintptr_t)a->out2_lo) % 8)
+      CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: res / out1 / out2 rows are accessed four channels at a time (ld, col multiples of 4)");
+  }
+  if (!i8 && a->out0_int8 && (a->epilogue != CUBE_EPI_GATE || !a->res || a->res_mode == 3 || !a->out0 || !a->out0_lo))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: out0_int8 needs the gate epilogue with a residual stream (res_mode 0..2) and both out0 planes");
   if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->A_lo) || !aligned16(a->W_lo))
     CUBE_FAIL(CUBE_ERR_ALIGN, "%s: operands must be 16-byte aligned", fn);
   ConvGroups cg;
@@ -710,6 +763,7 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   if (seq <= 0 || a->M % seq) CUBE_FAIL(CUBE_ERR_ARG, "%s: M=%d not a multiple of seq_len=%d", fn, a->M, seq);
   GemmParams p;
   p.vec_out = 0; p.m_tiles = p.n_tiles = 0;
+  p.out0_i8 = a->out0_int8;
   p.bias_tab = a->bias_tab; p.row_group = a->row_group;
   if ((a->bias_tab == nullptr) != (a->row_group == nullptr))
     CUBE_FAIL(CUBE_ERR_ARG, "%s: bias_tab and row_group go together", fn);
@@ -758,7 +812,7 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       p.vec_out = !a->res && a->out0 && half % 8 == 0 && a->ldo0 % 8 == 0 && a->col0 % 8 == 0 && aligned16(a->out0) &&
                   aligned16(a->out0_lo);
       if (i8) {
-        if (half % 16 || a->ldo0 % 16 || a->col0 % 16 || !aligned16(a->out0) || !aligned16(a->out0_lo))
+        if (half % 16 || (a->out0 && (a->ldo0 % 16 || a->col0 % 16 || !aligned16(a->out0) || !aligned16(a->out0_lo))))
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: out0 planes need 16-byte aligned rows (half, ldo0, col0 multiples of 16)");
         if (!aligned16(w_scale) || !aligned16(a->bias) || !aligned16(a->bias_tab))
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: w_scale, bias and bias_tab must be 16-byte aligned (read four floats at a time)");

