@@ -99,6 +99,7 @@ def test_gemm_i8x2_rejects_what_it_does_not_support(dev):
     from cube_amd import hip
     z = torch.zeros((64, 64), dtype=torch.int8, device=dev)
     w = hip.Pair(torch.zeros((128, 64), dtype=torch.int8, device=dev), torch.zeros((128, 64), dtype=torch.int8, device=dev))
+    w5 = hip.Pair(torch.zeros((128, 320), dtype=torch.int8, device=dev), torch.zeros((128, 320), dtype=torch.int8, device=dev))
     ws = torch.ones(128, device=dev)
     bias = torch.zeros(128, device=dev)
     out = hip.Pair(torch.zeros((64, 64), dtype=torch.int8, device=dev), torch.zeros((64, 64), dtype=torch.int8, device=dev))
@@ -106,9 +107,83 @@ def test_gemm_i8x2_rejects_what_it_does_not_support(dev):
         hip.gemm(hip.Pair(z, z), 64, 64, 32, w, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws)
     with pytest.raises(hip.CubeHipError):  # gate epilogue only
         hip.gemm(hip.Pair(z, z), 64, 64, 64, w, 128, bias, hip.EPI_BF16, out0=out, ldo0=64, n_valid=64, w_scale=ws)
-    with pytest.raises(hip.CubeHipError):  # no residual stream
-        hip.gemm(hip.Pair(z, z), 64, 64, 64, w, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws,
-                 res=torch.zeros((64, 64), device=dev), ld_res=64)
+    with pytest.raises(hip.CubeHipError, match="res_mode"):  # residual stream: res = g or res += g only
+        hip.gemm(hip.Pair(z, z), 64, 64, 64, w5, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws,
+                 res=torch.zeros((64, 64), device=dev), ld_res=64, res_mode=2, taps=5, seq_len=64)
+    with pytest.raises(hip.CubeHipError, match="four channels"):  # rows of res are read four channels at a time
+        hip.gemm(hip.Pair(z, z), 64, 64, 64, w5, 128, bias, hip.EPI_GATE, out0=out, ldo0=64, n_valid=64, w_scale=ws,
+                 res=torch.zeros((64, 66), device=dev), ld_res=66, res_mode=1, taps=5, seq_len=64)
+
+
+def test_word_level_int8x2_layers_match_float64(dev):
+    """The word-level stack's two int8x2 pieces through the C ABI: (1) cube_gemm_bf16 with `out0_int8` -- bf16x3
+    operands, fp32 residual stream, gate values out as int8x2 planes; (2) cube_gemm_i8x2 with the residual stream
+    (res += g) and the x + res side outputs.  Both against torch.conv1d in float64 on the operands the kernels see."""
+    from cube_amd import hip
+    from cube_amd.networks import packing
+    g = torch.Generator().manual_seed(5)
+    B, T, Kc, half, n_lang, nb = 7, 33, 256, 256, 3, 16
+    M = B * T
+
+    def conv_sd(cin):
+        w = torch.randn((2 * half, cin, 5), generator=g) / np.sqrt(5 * cin)
+        return {"c.0.conv.weight": w, "c.0.conv.bias": torch.randn(2 * half, generator=g) * 0.1,
+                "c.1.weight": torch.rand(2 * half, generator=g) + 0.5, "c.1.bias": torch.randn(2 * half, generator=g) * 0.1,
+                "c.1.running_mean": torch.randn(2 * half, generator=g) * 0.1, "c.1.running_var": torch.rand(2 * half, generator=g) + 0.5}
+
+    def folded(sd):
+        s = sd["c.1.weight"] / torch.sqrt(sd["c.1.running_var"] + 1e-5)
+        return (sd["c.0.conv.weight"] * s[:, None, None]).double(), ((sd["c.0.conv.bias"] - sd["c.1.running_mean"]) * s + sd["c.1.bias"]).double()
+
+    def gate(x, wf, bf):  # x [B, T, C] float64 -> [M, half]
+        co = torch.nn.functional.conv1d(x.permute(0, 2, 1), wf, bf, padding=2)
+        return (torch.tanh(co[:, :half]) * torch.sigmoid(co[:, half:])).permute(0, 2, 1).reshape(M, half)
+
+    # (1) layer 0: bf16x3 in, int8x2 planes + residual out
+    sd0 = conv_sd(Kc)
+    pk0 = packing.pack_gated_conv(sd0, "c", np.arange(Kc))
+    x0 = torch.randn((M, Kc), generator=g)
+    a0 = hip.Pair.split(x0)
+    x0q = (a0.hi.double() + a0.lo.double()).view(B, T, Kc)
+    w0 = packing.to_device(pk0["W"], dev)
+    wf0, bf0 = folded(sd0)
+    g0 = gate(x0q, wf0, bf0)
+    q0 = hip.Pair(torch.zeros((M, half), dtype=torch.int8, device=dev), torch.zeros((M, half), dtype=torch.int8, device=dev))
+    res = torch.full((M, half), 3.0, device=dev)
+    hip.gemm(a0.to(dev), Kc, M, pk0["Kc"], w0, pk0["N"], pk0["bias"].to(dev), hip.EPI_GATE, out0=q0, ldo0=half, taps=5,
+             seq_len=T, n_valid=half, res=res, ld_res=half, res_mode=0, out0_int8=True)
+    torch.cuda.synchronize()
+    got0 = (q0.hi.cpu().to(torch.int32) * 128 + q0.lo.cpu().to(torch.int32)).double() / hip.I8_ONE
+    np.testing.assert_allclose(got0.numpy(), g0.numpy(), rtol=0, atol=1e-4)          # 6.2e-5 output step + bf16x3
+    np.testing.assert_allclose(res.cpu().double().numpy(), g0.numpy(), rtol=0, atol=2e-5)   # res_mode 0: res = g
+    # (2) layer 1: int8x2 in, res += g, x + res into two bf16 hi/lo outputs, int8x2 planes out; language bias table
+    sd1 = conv_sd(Kc + nb)
+    table = torch.randn((n_lang, nb), generator=g)
+    pk1 = packing.pack_gated_conv(sd1, "c", np.arange(Kc), bcast=(Kc + np.arange(nb), table), int8=True)
+    lang = torch.randint(0, n_lang, (B,), generator=g)
+    lang_rows = lang.repeat_interleave(T).to(torch.int32)
+    wf1, bf1 = folded(sd1)
+    x1 = torch.cat([got0.view(B, T, Kc), table[lang].double()[:, None, :].expand(B, T, nb)], -1)
+    g1 = gate(x1, wf1, bf1)   # with the fp64 weights: the 15-bit weight rows add ~1e-5
+    q1 = hip.Pair(torch.zeros((M, half), dtype=torch.int8, device=dev), torch.zeros((M, half), dtype=torch.int8, device=dev))
+    o1 = hip.Pair(torch.zeros((M, half + 8), dtype=torch.bfloat16, device=dev), torch.zeros((M, half + 8), dtype=torch.bfloat16, device=dev))
+    o2 = hip.Pair(torch.zeros((M, half), dtype=torch.bfloat16, device=dev), torch.zeros((M, half), dtype=torch.bfloat16, device=dev))
+    res_before = res.cpu().double()
+    for out0 in (q1, None):   # the last layer of the stack has no gate output
+        res.copy_(res_before.float())
+        hip.gemm(q0, half, M, pk1["Kc"], packing.to_device(pk1["W8"], dev), pk1["N"], pk1["bias"].to(dev), hip.EPI_GATE,
+                 out0=out0, ldo0=half, taps=5, seq_len=T, n_valid=half, res=res, ld_res=half, res_mode=1,
+                 out1=o1, ldo1=half + 8, col1=4, out2=o2, ldo2=half, col2=0, bias_tab=pk1["bias_tab"].to(dev),
+                 row_group=lang_rows.to(dev), w_scale=pk1["w_scale"].to(dev))
+        torch.cuda.synchronize()
+        rs = res_before + g1
+        np.testing.assert_allclose(res.cpu().double().numpy(), rs.numpy(), rtol=0, atol=1e-4)
+        xs = (rs + g1).numpy()
+        np.testing.assert_allclose((o2.hi.cpu().double() + o2.lo.cpu().double()).numpy(), xs, rtol=0, atol=2e-4)
+        np.testing.assert_allclose((o1.hi.cpu().double() + o1.lo.cpu().double())[:, 4:4 + half].numpy(), xs, rtol=0, atol=2e-4)
+        assert (o1.hi.cpu()[:, :4] == 0).all() and (o1.hi.cpu()[:, 4 + half:] == 0).all()   # untouched
+    got1 = (q1.hi.cpu().to(torch.int32) * 128 + q1.lo.cpu().to(torch.int32)).double() / hip.I8_ONE
+    np.testing.assert_allclose(got1.numpy(), g1.numpy(), rtol=0, atol=1.5e-4)
 
 
 _CASES = [(cases.FULL, "full_8x32", "g3_forward_full.npz"), (cases.FULL, "full_2x128", "g3_forward_full.npz"),
