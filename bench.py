@@ -43,6 +43,7 @@ CONFIGS = {1: dict(B=256, L=32, name="en parser+tagger B=256 x L=32 (BASELINE co
                                                         "ranks, bucketed <=8192 tokens (BASELINE configs[3], SURVEY 8d config 3)")}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 I8_DENSE_PEAK_TOPS = 5000.0      # same table: I8 32x32x32 = 2x BF16 per clock
+SUSTAINED_I8_TOPS, SUSTAINED_BF16_TFLOPS = 3530.0, 1890.0  # measured, profiles/r2_mfma_peak.txt
 
 
 def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300,)):
@@ -189,6 +190,8 @@ def main():
     ap.add_argument("--precision", default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end process(Document) secondary number")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="profiling aid: skip the one-stream kernel-timing pass "
+                    "(the roofline then reports the events of the pipelined region)")
     ap.add_argument("--corpus-reps", type=int, default=64, help="config 3: repetitions of the 4096-sentence sample")
     ap.add_argument("--ext", default="1x300", help="external embeddings per word as KxE: 1x300 (fastText-like, the "
                     "BASELINE config) or 13x768 (xlm-roberta-base-like, SURVEY 8d secondary input)")
@@ -259,7 +262,7 @@ def main():
     # bracket the kernel alone (in the pipelined region above they also bracket the time the launch waits for CUs
     # held by the other stages' kernels, and the kernel shares the chip with them while it runs)
     kt_alone = None
-    if rank == 0 and args.config != 3:
+    if rank == 0 and args.config != 3 and not args.no_roofline_pass:
         n_alone = max(1, min(args.steps, 20))
         run_steps(p, batches, 2, serial=True)
         torch.cuda.synchronize()
@@ -312,6 +315,11 @@ def main():
                     executed_frac=(flops_executed / (ms * 1e-3) / 1e12 / peak) if ms else 0.0,
                     traffic_source=("PMC pass of this workload recorded in " + os.path.relpath(tf, ROOT)) if traffic else None, kernel_dtype="int8x2 (i32 accumulate)" if i8 else p.precision,
                     peak_is="dense int8 MFMA (2x bf16)" if i8 else "dense bf16 MFMA",
+                    # what the chip HOLDS with nothing but MFMAs on random operands (power limit; the nominal peak is reached
+                    # only with near-constant operands): scripts/micro/mfma_peak.hip, profiles/r2_mfma_peak.txt
+                    sustained_peak_measured=SUSTAINED_I8_TOPS if i8 else SUSTAINED_BF16_TFLOPS,
+                    executed_frac_of_sustained=(flops_executed / (ms * 1e-3) / 1e12 /
+                                                (SUSTAINED_I8_TOPS if i8 else SUSTAINED_BF16_TFLOPS)) if ms else 0.0,
                     frac_of_bf16_peak=achieved / BF16_DENSE_PEAK_TFLOPS,
                     kernel="gemm_kernel<GATE%s> (char conv, layers>=1)" % (", CfgI8, int8x2" if i8 else ""),
                     launches=kt_alone["n"], ms_per_launch=ms,

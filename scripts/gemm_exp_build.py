@@ -43,6 +43,22 @@ elif name == "EPI_NOTRANS":
 elif name == "EPI_NOSTORE":
     rep("        if (row >= 0 && cbase < p.n_valid) {\n          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes",
         "        if (row == -12345 && cbase < p.n_valid) {\n          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes")
+elif name == "NOB":  # upper bound for "weight fragments straight from L2 into registers": no weight DMA, no weight ds_reads
+    s = s.replace("*reinterpret_cast<const frag_t*>(bbase", "opaque_frag<frag_t>(bbase")
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+    rep("    glds16(p.W + b_src[I] + (size_t)(S) * BK, l_);                                            \\\n"
+        "    if constexpr (SPLIT) glds16(p.W_lo + b_src[I] + (size_t)(S) * BK, l_ + B_PLANE);          \\\n",
+        "    asm volatile(\"\" ::\"v\"(l_));                                            \\\n")
+elif name in ("NOFRAG_NODMA", "NOFRAG_NODMA_NOBAR", "NOBAR"):
+    if "NOFRAG" in name:
+        s = s.replace("*reinterpret_cast<const frag_t*>(", "opaque_frag<frag_t>(")
+        rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+        rep("""  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);""", """  asm volatile("" ::"v"(g), "v"(l));""")
+    if "NOBAR" in name:
+        rep("      if ((s & 1) || s == nk - 1) __syncthreads();", "      if (s == nk - 1) __syncthreads();")
 elif name == "PROF":  # wall-clock stamps (10 ns units) per workgroup of the int8x2 tile: entry, prologue done, loop done, end
     rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """__device__ long long g_gemm_prof[4 * 4096];
 template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
