@@ -779,8 +779,12 @@ class Parser(_HipNet):
         may be in flight (submitted, not collected)."""
         self._require_gpu()
         if self._streams is None:
-            n3 = self.N_SLOTS if os.environ.get("CUBE_STAGE3_STREAMS", "1") != "0" else 1
-            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(2 + n3))
+            # Three streams, one per stage, and no more: how HIP maps streams to its (by default 4) hardware queues
+            # depends on what else created streams in the process (RCCL under torch.distributed does), and two stages
+            # that land on one queue run one after the other.  A decode stream per slot was measured: 117k..159k
+            # sentences/s depending on GPU_MAX_HW_QUEUES and on whether RCCL was loaded; one decode stream:
+            # 154k..159k in all four combinations, and config 2 no slower (16.7k).
+            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
             self._slot_free = [None] * self.N_SLOTS
             self._host_res = [None] * self.N_SLOTS
             self._slot_busy = [False] * self.N_SLOTS
@@ -793,8 +797,7 @@ class Parser(_HipNet):
             raise hip.CubeHipError("Parser.submit: %d batches are in flight, collect() the oldest first" % self.N_SLOTS)
         self._slot_busy[slot] = True
         self._n_submitted += 1
-        s1, s2 = self._streams[:2]
-        s3 = self._streams[2 + slot % (len(self._streams) - 2)]  # the decode stage of each slot on a stream of its own
+        s1, s2, s3 = self._streams
         cur = torch.cuda.current_stream()
         B, L = bt["B"], bt["L"]
         with torch.cuda.stream(s1):
