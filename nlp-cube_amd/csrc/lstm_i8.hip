@@ -144,7 +144,6 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
     i32x4 acc[4], accs = {0, 0, 0, 0};
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (i32x4){0, 0, 0, 0};
-#ifndef EXP_NOMFMA
     // ---- HH, and the row sums of h_hi
 #pragma unroll
     for (int ks = 0; ks < KS64; ++ks) {
@@ -200,7 +199,6 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
       for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_16x16x32_i8(al, wt[g], acc[g], 0, 0, 0);
       SCHED_FENCE();
     }
-#endif
     // ---- gates (the input projections of this step have landed in LDS by now)
     if constexpr (GXL) {
       // all sixteen values out of LDS first, then the request for the NEXT step goes out before the gate math instead
@@ -210,12 +208,10 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gxv[g][r] = *reinterpret_cast<const float*>(gx_mine + (g * 4 + r) * 256 + lane * 4);
-#ifndef EXP_NOGX
       if (s + 1 < T) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are done before the DMA rewrites the area
         fetch_gx(dir ? t - 1 : t + 1);
       }
-#endif
     }
     unsigned char* hn = s_h + (cur ^ 1) * 2 * HIMG;
 #pragma unroll
@@ -224,16 +220,11 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
       const float pf = (float)acc[1][r] * sc[1] + gxv[1][r];
       const float pg = fminf(fmaxf((float)acc[2][r] * sc[2] + gxv[2][r], -15.f), 15.f);
       const float po = (float)acc[3][r] * sc[3] + gxv[3][r];
-#ifdef EXP_NOGATE
-      c[r] += pi + pf + pg;
-      const float hf = fminf(fmaxf(po + c[r], -0.9f), 0.9f);
-#else
       const float eg = __expf(-2.0f * pg);
       const float ig_gg = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + __expf(-pi)) * (1.0f + eg));
       c[r] = sigmoidf_(pf) * c[r] + ig_gg;
       const float ec = __expf(-2.0f * fminf(fmaxf(c[r], -15.f), 15.f));
       const float hf = (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + __expf(-po)) * (1.0f + ec));
-#endif
       int q = __float2int_rn(hf * (float)CUBE_I8_ONE);
       q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
       const int qh = (q + 64) >> 7;  // arithmetic shift = floor: hi in [-127, 127], lo in [-64, 63]
@@ -249,10 +240,8 @@ __global__ __launch_bounds__(64 * U) void bilstm_i8_kernel(const float* __restri
         if (out_lo) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(out_lo) + ob + oo) = hl;
       }
     }
-#ifndef EXP_NOGX
     if constexpr (!GXL)
       if (s + 1 < T) fetch_gx(dir ? t - 1 : t + 1);
-#endif
     __syncthreads();
     cur ^= 1;
   }
