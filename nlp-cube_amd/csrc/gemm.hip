@@ -140,7 +140,9 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 // channels instead of 32 and every address below is unchanged when counted in 2-byte units (the host
 // passes lda/2 and Kc/2); x = 128*hi + lo, the products hi*hi and hi*lo + lo*hi accumulate exactly
 // in two int32 sets (v_mfma_i32_32x32x32_i8, twice the bf16 rate) and are combined in the epilogue.
-template <int EPI, bool SPLIT, class C, bool I8 = false>
+// RES8 (int8x2 only): the epilogue carries the fp32 residual stream and the x + res side outputs (word-level stack); a
+// template parameter so that the character-CNN launches keep their lean epilogue and their own kernel name in traces
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>
 __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg, const ConvTiles ct) {
   static_assert(!I8 || (SPLIT && EPI == CUBE_EPI_GATE), "int8x2 is built for the gated convolutions only");
   using acc_t = typename std::conditional<I8, i32x16, f32x16>::type;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
           }
           *reinterpret_cast<uint32_t*>(stg + l31 * SROW8 + 8 * g + 4 * lh) = dh;
           *reinterpret_cast<uint32_t*>(stg + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
-          if (res) {  // word-level stack: fp32 residual stream (res_mode 0: = g, 1: += g) and the x + res side outputs
+          if constexpr (RES8) {  // word-level stack: fp32 residual stream (res_mode 0: = g, 1: += g) and the x + res side outputs
             const int c0 = chb + 8 * g + 4 * lh;  // four consecutive channels of this lane's row
             if (orow_l >= 0 && c0 < p.n_valid) {
               float* rp = res + (size_t)orow_l * p.ld_res + c0;
@@ -669,18 +671,18 @@ inline int count_row_tiles(int M, const ConvGroups& cg, int BM, int SR, ConvTile
 
 constexpr int NUM_CUS = 256;
 
-template <int EPI, bool SPLIT, class C, bool I8 = false>
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>
 int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   constexpr int lds = lds_bytes<C, SPLIT>();
   static CubeLdsReservation reserved;
-  if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C, I8>, lds))
+  if (!reserved.ensure((const void*)gemm_kernel<EPI, SPLIT, C, I8, RES8>, lds))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_gemm_bf16: cannot reserve %d bytes of LDS", lds);
   p.n_tiles = p.N / C::BN;
   ConvTiles ct = {};
   p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR, &ct);
   if (p.m_tiles < 0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: a sequence group does not fit the activation slab");
   dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
-  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg, ct);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8, RES8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg, ct);
   return CUBE_OK;
 }
 
@@ -816,7 +818,8 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: out0 planes need 16-byte aligned rows (half, ldo0, col0 multiples of 16)");
         if (!aligned16(w_scale) || !aligned16(a->bias) || !aligned16(a->bias_tab))
           CUBE_FAIL(CUBE_ERR_ALIGN, "cube_gemm_i8x2: w_scale, bias and bias_tab must be 16-byte aligned (read four floats at a time)");
-        rc = launch_cfg<CUBE_EPI_GATE, true, CfgI8, true>(p, cg, st);
+        rc = a->res ? launch_cfg<CUBE_EPI_GATE, true, CfgI8, true, true>(p, cg, st)
+                    : launch_cfg<CUBE_EPI_GATE, true, CfgI8, true, false>(p, cg, st);
         break;
       }
       rc = launch<CUBE_EPI_GATE>(p, cg, st);
