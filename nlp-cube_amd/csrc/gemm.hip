@@ -180,8 +180,12 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   int row_lo = 0, seq = p.seq_len, seq_out = p.seq_len, row0_out = 0, word0 = 0;
   int n_out = p.M, ro0 = mt * BM, bm = BM;
   if (cg.n > 0) {
+    // tile0 is non-decreasing: g = how many groups start at or before this tile.  Constant indices, so the table comes in
+    // with two wide scalar loads and the search is 31 scalar compares (a data-dependent loop reads it one dependent
+    // scalar load at a time: about a microsecond of every workgroup's prologue)
     int g = 0;
-    while (g + 1 < cg.n && mt >= ct.tile0[g + 1]) ++g;
+#pragma unroll
+    for (int i = 1; i < CUBE_MAX_CONV_GROUPS; ++i) g += (i < cg.n && mt >= ct.tile0[i]) ? 1 : 0;
     const int t0 = ct.tile0[g];
     bm = ct.bm[g];
     n_out = ct.n_out[g];

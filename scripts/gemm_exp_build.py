@@ -23,8 +23,8 @@ if name == "NOMFMA":
         '''          asm volatile("" ::"v"(fa[u % AR][1]), "v"(fa[u % AR][0]), "v"(fb[ks][0][j]), "v"(fb[ks][1][j]));''')
 elif name == "NOFRAG":
     s = s.replace("*reinterpret_cast<const frag_t*>(", "opaque_frag<frag_t>(")
-    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", '''template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
-template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__''')
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__", '''template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__''')
 elif name == "NODMA":
     rep('''  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);''', '''  asm volatile("" ::"v"(g), "v"(l));''')
@@ -45,30 +45,30 @@ elif name == "EPI_NOSTORE":
         "        if (row == -12345 && cbase < p.n_valid) {\n          const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes")
 elif name == "NOB":  # upper bound for "weight fragments straight from L2 into registers": no weight DMA, no weight ds_reads
     s = s.replace("*reinterpret_cast<const frag_t*>(bbase", "opaque_frag<frag_t>(bbase")
-    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
-template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__""")
     rep("    glds16(p.W + b_src[I] + (size_t)(S) * BK, l_);                                            \\\n"
         "    if constexpr (SPLIT) glds16(p.W_lo + b_src[I] + (size_t)(S) * BK, l_ + B_PLANE);          \\\n",
         "    asm volatile(\"\" ::\"v\"(l_));                                            \\\n")
 elif name in ("NOFRAG_NODMA", "NOFRAG_NODMA_NOBAR", "NOBAR"):
     if "NOFRAG" in name:
         s = s.replace("*reinterpret_cast<const frag_t*>(", "opaque_frag<frag_t>(")
-        rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
-template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+        rep("template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__", """template <class F> __device__ __forceinline__ F opaque_frag(const void*) { F z; asm volatile("" : "=v"(z)); return z; }
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__""")
         rep("""  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);""", """  asm volatile("" ::"v"(g), "v"(l));""")
     if "NOBAR" in name:
         rep("      if ((s & 1) || s == nk - 1) __syncthreads();", "      if (s == nk - 1) __syncthreads();")
 elif name == "PROF":  # wall-clock stamps (10 ns units) per workgroup of the int8x2 tile: entry, prologue done, loop done, end
-    rep("template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__", """__device__ long long g_gemm_prof[4 * 4096];
-template <int EPI, bool SPLIT, class C, bool I8 = false>\n__global__""")
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__", """__device__ long long g_gemm_prof[4 * 4096];
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__""")
     rep("  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  constexpr int BM = C::BM, BN = C::BN;",
         "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  const long long t0_ = wall_clock64();\n  constexpr int BM = C::BM, BN = C::BN;")
     rep("  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables",
         "  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables\n  const long long t1_ = wall_clock64();")
     rep("  // ---- epilogue.  C/D map of 32x32x16:", "  const long long t2_ = wall_clock64();\n  // ---- epilogue.  C/D map of 32x32x16:")
-    rep("        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n      }\n      return;",
-        "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n      }\n"
+    rep("          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n          __builtin_amdgcn_wave_barrier();\n        }\n      }\n      return;",
+        "          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n          __builtin_amdgcn_wave_barrier();\n        }\n      }\n"
         "      if (I8 && tid == 0 && blockIdx.x < 4096) { long long* q_ = g_gemm_prof + 4 * blockIdx.x; q_[0] = t0_; q_[1] = t1_; q_[2] = t2_; q_[3] = wall_clock64(); }\n      return;")
     s += """
 extern "C" int cube_gemm_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 4 * 4096) == hipSuccess ? 0 : 1; }
