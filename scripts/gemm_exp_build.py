@@ -73,6 +73,19 @@ template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__g
     s += """
 extern "C" int cube_gemm_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 4 * 4096) == hipSuccess ? 0 : 1; }
 """
+elif name == "PROF2":  # stamps inside the prologue: entry, before the first DMA issue, after it, after the row tables, after the barrier
+    rep("template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__", """__device__ long long g_gemm_prof[8 * 4096];
+template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>\n__global__""")
+    rep("  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  constexpr int BM = C::BM, BN = C::BN;",
+        "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n  const long long t0_ = wall_clock64();\n  constexpr int BM = C::BM, BN = C::BN;")
+    rep("  ISSUE_A(0, 0)\n  ISSUE_B(0, 0)", "  const long long ta_ = wall_clock64();\n  ISSUE_A(0, 0)\n  ISSUE_B(0, 0)")
+    rep("  if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;", "  const long long tb_ = wall_clock64();\n  if (tid < ROWB / 4) reinterpret_cast<uint32_t*>(smem + ZERO_OFF)[tid] = 0u;")
+    rep("  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables",
+        "  const long long tc_ = wall_clock64();\n  __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables\n  const long long t1_ = wall_clock64();\n"
+        "  if (I8 && !RES8 && tid == 0 && blockIdx.x < 4096) { long long* q_ = g_gemm_prof + 8 * blockIdx.x; q_[0] = t0_; q_[1] = ta_; q_[2] = tb_; q_[3] = tc_; q_[4] = t1_; }")
+    s += """
+extern "C" int cube_gemm_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 8 * 4096) == hipSuccess ? 0 : 1; }
+"""
 elif name != "BASE":
     raise SystemExit("unknown variant")
 os.makedirs(os.path.join(ROOT, "ab_tmp"), exist_ok=True)
