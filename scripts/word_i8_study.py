@@ -29,6 +29,11 @@ def rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
+def rel_elem(a, b, floor):
+    """element-wise relative error with a floor on the denominator (a fraction of the largest score)"""
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor * np.abs(b).max())).max())
+
+
 for name, flags in (("all int8x2", {}), ("word bf16x3", dict(word_int8=False)), ("word+lstm bf16x3", dict(word_int8=False, lstm_int8=False)),
                     ("all bf16x3", dict(word_int8=False, lstm_int8=False, char_int8=False))):
     p = Parser(cfg, enc, ext_word_emb=[300])
@@ -42,3 +47,6 @@ for name, flags in (("all int8x2", {}), ("word bf16x3", dict(word_int8=False)), 
         name, rel(r["arc_logits"].cpu().numpy(), e["arc_logits"]), rel(r["label_logits"].cpu().numpy(), e["label_logits"]),
         rel(r["upos_logits"].cpu().numpy(), e["upos_logits"]), (heads == ref_heads).mean(), int((heads != ref_heads).sum()),
         int((heads != ref_heads).any(axis=1).sum())), flush=True)
+    a = r["arc_logits"].cpu().numpy()
+    print("%-18s arc element-wise, denominator floored at 10 %% / 1 %% of the largest score: %.2e / %.2e" % (
+        "", rel_elem(a, e["arc_logits"], 0.1), rel_elem(a, e["arc_logits"], 0.01)), flush=True)
