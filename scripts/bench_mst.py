@@ -21,7 +21,16 @@ fn.restype = ctypes.c_int
 fn.argtypes = hip.SIGNATURES["cube_mst_decode"][1]
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-probs = torch.softmax(torch.randn((B, L, L + 1), generator=g) * sigma, -1).to(dev).contiguous()
+if os.environ.get("MST_BENCH_MODEL") == "1":
+    # the arc probabilities of the bench's own first batch (random-init full-size model): what bench.py's decode stage sees
+    import bench
+    cfg_id = {(256, 32): 1, (64, 128): 2}[(B, L)]
+    p_, *_rest, batches, _docs = bench.build_model_and_batches(cfg_id, 1, 0, dev, "")
+    r_ = p_.decode_batch_prepared(batches[0])
+    probs = r_["arc_probs"].clone().contiguous()
+    del p_, r_
+else:
+    probs = torch.softmax(torch.randn((B, L, L + 1), generator=g) * sigma, -1).to(dev).contiguous()
 lens = torch.full((B,), L, dtype=torch.int32, device=dev)
 heads = torch.empty((B, L), dtype=torch.int32, device=dev)
 status = torch.empty((B,), dtype=torch.int32, device=dev)
