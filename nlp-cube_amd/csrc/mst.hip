@@ -45,7 +45,8 @@ constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160
 constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences, node ids still bytes: S lives in the workspace (HBM/L2), slow but exact
 constexpr int MST_MAX_N_LONG = 2048;   // beyond 254 words: 16-bit node ids, S and the contraction records in the workspace
 constexpr size_t MST_LONG_ROOT_BYTES = (size_t)2 << 30;  // workspace the rooted re-runs of such a batch may take
-constexpr int MST_GLOBAL_ROOT_BLOCKS = 1792;  // workgroups (= private score matrices) of the root kernel in that mode: 7 per CU
+constexpr int MST_GLOBAL_ROOT_BLOCKS = 3072;  // workgroups (= private score matrices) of the root kernel in that mode: 12 per CU
+// (its contraction records live in the workspace too, so a task holds 6 KB of LDS and the ~150 VGPRs of the kernel set the limit)
 // The rooted re-runs (one task per candidate root, ~17 per sentence when most first trees are not
 // single-rooted) switch to workspace-resident score matrices earlier: from this size on an LDS-resident
 // matrix leaves one or two tasks per CU, and a task is bound by its own dependent-access latency, not
@@ -64,10 +65,10 @@ struct MstLdsT {
 __host__ __device__ inline int mst_np(int n) { return (n + 7) & ~7; }
 __host__ __device__ inline size_t mst_rec_cap(int n) { return (size_t)n * n + 3 * (size_t)n + 16; }
 // LDS of one task; `id` = bytes per node id; 2-byte ids keep their contraction records in the workspace as well
-__host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false, int id = 1) {
+__host__ __device__ inline size_t mst_lds_bytes(int n, bool global_s = false, int id = 1, bool global_rec = false) {
   const int ld = n | 1;
   const int np = mst_np(n);
-  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)4 * np * 8 + (size_t)14 * np * id + (id == 1 ? mst_rec_cap(n) : 0);
+  return (global_s ? 0 : (size_t)n * ld * 8) + (size_t)4 * np * 8 + (size_t)14 * np * id + (global_rec ? 0 : id * mst_rec_cap(n));
 }
 
 template <typename IdT>
@@ -478,8 +479,8 @@ struct MstWs {
   void* task_tree;      // [B*L][L+1] node ids (1 or 2 bytes each)
   double* s_first;      // long-sentence mode only: [B][n_max * ld] score matrices of the first pass
   double* s_root;       // and [mst_root_blocks][n_max * ld] of the root pass
-  uint16_t* rec_first;  // 16-bit ids only: [B][rec_cap] contraction records of the first pass
-  uint16_t* rec_root;   // and [mst_root_blocks][rec_cap] of the root pass
+  unsigned char* rec_first;  // 16-bit ids only: [B][rec_cap] contraction records of the first pass
+  unsigned char* rec_root;   // workspace-resident root pass: [mst_root_blocks][rec_cap] records (1- or 2-byte ids)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -494,13 +495,15 @@ __host__ inline size_t mst_root_blocks(int B, int L) {  // workgroups of the roo
   }
   return nt < cap ? nt : cap;
 }
+__host__ __device__ inline size_t mst_rec_stride(int T, int id) { return align16((size_t)id * mst_rec_cap(T)); }  // bytes per task
 __host__ inline size_t mst_ws_bytes(int B, int L) {
   const size_t nt = (size_t)B * L;
   const int id = mst_id_bytes(L);
   size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1) * id);
   if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * (size_t)B;
   if (L + 1 >= MST_ROOT_GLOBAL_N) b += 8 * mst_s_elems(L) * mst_root_blocks(B, L);
-  if (id == 2) b += align16(2 * mst_rec_cap(L + 1)) * ((size_t)B + mst_root_blocks(B, L));
+  if (id == 2) b += mst_rec_stride(L + 1, 2) * (size_t)B;
+  if (L + 1 >= MST_ROOT_GLOBAL_N) b += mst_rec_stride(L + 1, id) * mst_root_blocks(B, L);
   return b;
 }
 __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
@@ -516,19 +519,20 @@ __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
   w.task_tree = (void*)q; q += align16(nt * (L + 1) * mst_id_bytes(L));
   w.s_first = (double*)q;
   w.s_root = w.s_first + (L + 1 > MST_MAX_N ? mst_s_elems(L) * B : 0);
-  w.rec_first = (uint16_t*)(w.s_root + (L + 1 >= MST_ROOT_GLOBAL_N ? mst_s_elems(L) * mst_root_blocks(B, L) : 0));
-  w.rec_root = w.rec_first + align16(2 * mst_rec_cap(L + 1)) / 2 * (size_t)B;
+  w.rec_first = (unsigned char*)(w.s_root + (L + 1 >= MST_ROOT_GLOBAL_N ? mst_s_elems(L) * mst_root_blocks(B, L) : 0));
+  w.rec_root = w.rec_first + (mst_id_bytes(L) == 2 ? mst_rec_stride(L + 1, 2) * (size_t)B : 0);
   return w;
 }
 
-// the per-task slice of the 16-bit contraction records (byte ids keep them in LDS)
-template <typename IdT>
-__device__ __forceinline__ IdT* mst_rec_slice(uint16_t* base, size_t task, int T) {
-  if constexpr (sizeof(IdT) == 2) return base + task * (align16(2 * mst_rec_cap(T)) / 2);
+// the per-task slice of the contraction records in the workspace (GREC; otherwise they are in LDS)
+template <typename IdT, bool GREC>
+__device__ __forceinline__ IdT* mst_rec_slice(unsigned char* base, size_t task, int T) {
+  if constexpr (GREC) return reinterpret_cast<IdT*>(base + task * mst_rec_stride(T, (int)sizeof(IdT)));
   else return nullptr;
 }
 
-template <bool GS, typename IdT>  // GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words)
+// GS: score matrix in the workspace instead of LDS (sentences longer than MST_MAX_N - 1 words); GREC: the records too
+template <bool GS, typename IdT, bool GREC>
 __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel(const float* __restrict__ probs,
                                                                        const int32_t* __restrict__ lens, int B, int L,
                                                                        int32_t* heads, int32_t* status, MstWs ws,
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
   if (lane == 0) { ws.sent_cnt[b] = 0; ws.sent_base[b] = 0; status[b] = 0; }
   if (len == 0) return;
   const float* p = probs + (size_t)b * L * T;
-  MstLdsT<IdT> m = mst_carve<IdT>(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr, mst_rec_slice<IdT>(ws.rec_first, b, T));
+  MstLdsT<IdT> m = mst_carve<IdT>(smem, n, GS ? ws.s_first + (size_t)b * T * (T | 1) : nullptr, mst_rec_slice<IdT, GREC>(ws.rec_first, b, T));
   const bool has_nan = build_scores(m, p, n, T, lane, 0);
   if (!cle_run(m, n, lane, has_nan)) { if (lane == 0) status[b] = 2; return; }
   MST_SYNC();
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
   }
 }
 
-template <bool GS, typename IdT>
+template <bool GS, typename IdT, bool GREC>
 __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
                                                                       const int32_t* __restrict__ lens, int B, int L, MstWs ws,
                                                                       int lds_task) {
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
     MstLdsT<IdT> m = mst_carve<IdT>(smem, n, GS ? ws.s_root + (size_t)(blockIdx.x * wpb + wave) * T * (T | 1) : nullptr,
-                                    mst_rec_slice<IdT>(ws.rec_root, blockIdx.x * wpb + wave, T));
+                                    mst_rec_slice<IdT, GREC>(ws.rec_root, blockIdx.x * wpb + wave, T));
     const bool has_nan = build_scores(m, p, n, T, lane, root);
     IdT* tt = reinterpret_cast<IdT*>(ws.task_tree) + (size_t)t * T;
     if (!cle_run(m, n, lane, has_nan)) {
@@ -699,8 +703,9 @@ template <bool GS_FIRST, bool GS_ROOT, typename IdT>
 int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* heads, int32_t* status, const MstWs& ws,
                hipStream_t st) {
   constexpr int ID = (int)sizeof(IdT);
-  const size_t task_first = (mst_lds_bytes(L + 1, GS_FIRST, ID) + 15) & ~(size_t)15;
-  const size_t task_root = (mst_lds_bytes(L + 1, GS_ROOT, ID) + 15) & ~(size_t)15;
+  constexpr bool GREC_FIRST = ID == 2, GREC_ROOT = GS_ROOT;  // records in the workspace
+  const size_t task_first = (mst_lds_bytes(L + 1, GS_FIRST, ID, GREC_FIRST) + 15) & ~(size_t)15;
+  const size_t task_root = (mst_lds_bytes(L + 1, GS_ROOT, ID, GREC_ROOT) + 15) & ~(size_t)15;
   // tasks per workgroup: as many as the CU's LDS holds (workspace-resident matrices: one, their blocks index the workspace)
   auto waves = [](size_t task, bool gs) {
     if (gs) return 1;
@@ -710,11 +715,11 @@ int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* h
   const int w_first = waves(task_first, GS_FIRST), w_root = waves(task_root, GS_ROOT);
   const size_t lds_first = task_first * w_first, lds_root = task_root * w_root;
   static CubeLdsReservation reserved[2];
-  if (!reserved[0].ensure((const void*)mst_first_kernel<GS_FIRST, IdT>, lds_first) ||
-      !reserved[1].ensure((const void*)mst_root_kernel<GS_ROOT, IdT>, lds_root))
+  if (!reserved[0].ensure((const void*)mst_first_kernel<GS_FIRST, IdT, GREC_FIRST>, lds_first) ||
+      !reserved[1].ensure((const void*)mst_root_kernel<GS_ROOT, IdT, GREC_ROOT>, lds_root))
     CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: cannot reserve %zu bytes of LDS", lds_first > lds_root ? lds_first : lds_root);
   if (hipMemsetAsync(ws.ntasks, 0, 16, st) != hipSuccess) CUBE_FAIL(CUBE_ERR_LAUNCH, "cube_mst_decode: memset failed");
-  hipLaunchKernelGGL((mst_first_kernel<GS_FIRST, IdT>), dim3((B + w_first - 1) / w_first), dim3(64 * w_first), lds_first, st, probs,
+  hipLaunchKernelGGL((mst_first_kernel<GS_FIRST, IdT, GREC_FIRST>), dim3((B + w_first - 1) / w_first), dim3(64 * w_first), lds_first, st, probs,
                      lens, B, L, heads, status, ws, (int)task_first);
   CUBE_CHECK_LAUNCH("cube_mst_decode(first)");
   // one task per candidate root, at most B*L of them; the grid strides over the device-side count
@@ -726,7 +731,7 @@ int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* h
     const int cap = w_root > 1 ? MST_ROOT_MAX_BLOCKS : 4096;
     if (nblk > cap) nblk = cap;
   }
-  hipLaunchKernelGGL((mst_root_kernel<GS_ROOT, IdT>), dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws,
+  hipLaunchKernelGGL((mst_root_kernel<GS_ROOT, IdT, GREC_ROOT>), dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws,
                      (int)task_root);
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
   hipLaunchKernelGGL(mst_select_kernel<IdT>, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
