@@ -111,6 +111,11 @@ typedef struct cube_gemm_args {
   const cube_conv_groups* groups;   /* optional, host memory */
   int out0_int8;             /* cube_gemm_bf16, gate epilogue with res: out0 / out0_lo are int8x2 planes of the gate value
                                 (ldo0, col0 in bytes) for a next layer that runs in cube_gemm_i8x2 */
+  /* batch > 1 (cube_gemm_bf16, Linear layers: taps 1, no gate / rowmap / groups): `batch` problems of the same shape in
+   * ONE launch -- problem z reads A + z*stride_A, W + z*stride_W (elements, both planes), bias + z*stride_bias and writes
+   * out0 at column col0 + z*stride_col0.  Several GEMMs that each fill a fraction of the chip (the first layers of the K
+   * external-embedding MLPs, parser.py:130-138) then run on the large tiles as one grid.  0 and 1 mean one problem. */
+  int batch; long long stride_A; long long stride_W; int stride_bias; int stride_col0;
 } cube_gemm_args;
 int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 
@@ -171,11 +176,12 @@ int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const 
                         int ld_x, const int32_t* len, int N, int W, int C,
                         void* out, void* out_lo, int ld_out, const int32_t* word_rows, void* stream);
 
-/* e = tanh(acc[r, 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i);
+/* e = tanh(sum_j acc[r, j*part_stride + 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i; j < parts, summed in
+ * that order: parts = 1 when the GEMMs accumulated in place, parts = K after one batched launch of the K second layers);
  * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);
  * root = 1: the destination keeps a root row in front of every sentence (parser.py:195-197),
  * root = 0: it does not (tagger.py:111-119).  dst_b may be NULL.                            */
-int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K,
+int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, int parts, int part_stride,
                     void* dst_a, void* dst_a_lo, int ld_a, int col_a,
                     void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream);
 

@@ -94,6 +94,7 @@ struct GemmParams {
   uint16_t* out2; uint16_t* out2_lo; int ldo2; int col2;
   int m_tiles; int n_tiles;  // set by launch_cfg
   int vec_out;               // gate epilogue without residual: 16-byte row-contiguous stores are legal
+  int batch; long bs_a; long bs_w; int bs_bias; int bs_col0;  // batched Linear layers: problem z = blockIdx.y (strides in elements)
   int out0_i8;               // bf16 operands, gate epilogue with residual: out0 = int8x2 planes of the gate value (ldo0, col0 in bytes)
   const float* bias_tab; const int32_t* row_group;  // row-dependent bias (broadcast channels folded in)
   const float* w_scale;      // int8x2 only: per packed column, value of one unit of 128*hh + (hl + lh)
@@ -143,7 +144,16 @@ __device__ __forceinline__ void glds16(const uint16_t* g, unsigned char* l) {
 // RES8 (int8x2 only): the epilogue carries the fp32 residual stream and the x + res side outputs (word-level stack); a
 // template parameter so that the character-CNN launches keep their lean epilogue and their own kernel name in traces
 template <int EPI, bool SPLIT, class C, bool I8 = false, bool RES8 = false>
-__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p, const ConvGroups cg, const ConvTiles ct) {
+__global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmParams p_in, const ConvGroups cg, const ConvTiles ct) {
+  GemmParams p = p_in;
+  if (p.batch > 1) {  // same-shape problems side by side in grid.y (uniform: scalar arithmetic)
+    const long z = blockIdx.y;
+    p.A += z * p.bs_a;
+    p.W += z * p.bs_w;
+    if (p.A_lo) { p.A_lo += z * p.bs_a; p.W_lo += z * p.bs_w; }
+    if (p.bias) p.bias += z * p.bs_bias;
+    p.col0 += (int)z * p.bs_col0;
+  }
   static_assert(!I8 || (SPLIT && EPI == CUBE_EPI_GATE), "int8x2 is built for the gated convolutions only");
   using acc_t = typename std::conditional<I8, i32x16, f32x16>::type;
   using frag_t = typename std::conditional<I8, i32x4, bf16x8>::type;
@@ -685,7 +695,7 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
   ConvTiles ct = {};
   p.m_tiles = count_row_tiles(p.M, cg, C::BM, C::SR, &ct);
   if (p.m_tiles < 0) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_bf16: a sequence group does not fit the activation slab");
-  dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8));
+  dim3 grid(p.n_tiles * ((p.m_tiles + 7) / 8 * 8), p.batch > 1 ? p.batch : 1);
   hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT, C, I8, RES8>), grid, dim3(64 * C::WM * C::WN), lds, st, p, cg, ct);
   return CUBE_OK;
 }
@@ -693,7 +703,8 @@ int launch_cfg(GemmParams p, const ConvGroups& cg, hipStream_t st) {
 template <int EPI, bool SPLIT>
 int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
   // the big tiles need enough row tiles to fill the 256 CUs
-  const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) >= 192);
+  const long nb = p.batch > 1 ? p.batch : 1;  // problems in the grid
+  const bool big = (p.N % CfgBig::BN == 0) && ((long)(p.M / CfgBig::BM) * (p.N / CfgBig::BN) * nb >= 192);
   if (!big) {
     if constexpr (EPI == CUBE_EPI_GATE) {
       // a convolution whose 128-row tiles are a little more than one block per CU: 160-row tiles, one round
@@ -710,7 +721,7 @@ int launch_split(const GemmParams& p, const ConvGroups& cg, hipStream_t st) {
   const long nt = p.N / CfgBig::BN;
   auto cost = [&](int BM, int SR, double penalty) {
     const int t = count_row_tiles(p.M, cg, BM, SR);
-    return t < 0 ? 1e30 : (double)((t * nt + NUM_CUS - 1) / NUM_CUS) * BM * penalty;
+    return t < 0 ? 1e30 : (double)((t * nt * nb + NUM_CUS - 1) / NUM_CUS) * BM * penalty;
   };
   if (cost(CfgBig192::BM, CfgBig192::SR, 1.04) < cost(CfgBig::BM, CfgBig::SR, 1.0))
     return launch_cfg<EPI, SPLIT, CfgBig192>(p, cg, st);
@@ -770,6 +781,16 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
   GemmParams p;
   p.vec_out = 0; p.m_tiles = p.n_tiles = 0;
   p.out0_i8 = a->out0_int8;
+  p.batch = a->batch > 1 ? a->batch : 1; p.bs_a = (long)a->stride_A; p.bs_w = (long)a->stride_W; p.bs_bias = a->stride_bias;
+  p.bs_col0 = a->stride_col0;
+  if (p.batch > 1) {
+    if (i8 || a->epilogue == CUBE_EPI_GATE || a->taps != 1 || a->rowmap || a->groups || a->accumulate || p.batch > 65535)
+      CUBE_FAIL(CUBE_ERR_ARG, "%s: batch=%d is for plain Linear layers (taps 1, no gate epilogue / rowmap / groups / accumulate)", fn, a->batch);
+    if (a->stride_A % 8 || a->stride_W % 8 || a->stride_A < 0 || a->stride_W < 0 || a->stride_bias < 0 || a->stride_col0 < 0)
+      CUBE_FAIL(CUBE_ERR_ALIGN, "%s: batch strides of A and W must be non-negative multiples of 8 elements", fn);
+    if (a->ldo0 < a->col0 + (p.batch - 1) * a->stride_col0 + (a->n_valid > 0 ? a->n_valid : a->N))
+      CUBE_FAIL(CUBE_ERR_ARG, "%s: ldo0=%d does not hold %d problems at column stride %d", fn, a->ldo0, p.batch, a->stride_col0);
+  }
   p.bias_tab = a->bias_tab; p.row_group = a->row_group;
   if ((a->bias_tab == nullptr) != (a->row_group == nullptr))
     CUBE_FAIL(CUBE_ERR_ARG, "%s: bias_tab and row_group go together", fn);

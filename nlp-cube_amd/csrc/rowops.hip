@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 12; }
+extern "C" int cube_abi_version(void) { return 13; }
 
 namespace {
 
@@ -212,14 +212,17 @@ __global__ __launch_bounds__(256) void masked_mean_i8_kernel(MeanLayers ly, int 
   }
 }
 
-__global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K,
+__global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K, int parts,
+                                                         int part_stride,
                                                          uint16_t* da, uint16_t* da_lo, int ld_a, int col_a,
                                                          uint16_t* db, uint16_t* db_lo, int ld_b, int col_b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * L * P) return;
   const int r = t / P, c = t - r * P;
   const int b = r / L, i = r - b * L;
-  const float e = tanhf_(acc[(size_t)r * ld_acc + c] / K);
+  float sum = acc[(size_t)r * ld_acc + c];
+  for (int j = 1; j < parts; ++j) sum += acc[(size_t)r * ld_acc + (size_t)j * part_stride + c];  // in the order of the LM layers
+  const float e = tanhf_(sum / K);
   uint16_t v, vl;
   split_bf16(e, v, vl);
   const size_t orow = (size_t)b * (L + root) + i + root;
@@ -396,15 +399,18 @@ extern "C" int cube_masked_mean_i8(const void* const* x_hi, const void* const* x
   return masked_mean_entry(true, x_hi, x_lo, weight, n_layers, ld_x, len, N, W, C, out, out_lo, ld_out, word_rows, stream);
 }
 
-extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, void* dst_a, void* dst_a_lo,
-                               int ld_a, int col_a, void* dst_b, void* dst_b_lo, int ld_b, int col_b, void* stream) {
+extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P, int K, int parts, int part_stride,
+                               void* dst_a, void* dst_a_lo, int ld_a, int col_a, void* dst_b, void* dst_b_lo, int ld_b, int col_b,
+                               void* stream) {
   CUBE_ENTRY();
   if (B <= 0 || L <= 0 || P <= 0) return CUBE_OK;
   if (!acc || K <= 0 || P > ld_acc || (root != 0 && root != 1)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad args");
+  if (parts < 1 || (parts > 1 && (part_stride < P || (long)(parts - 1) * part_stride + P > ld_acc)))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: %d parts of stride %d do not fit rows of %d", parts, part_stride, ld_acc);
   if ((dst_a && col_a + P > ld_a) || (dst_b && col_b + P > ld_b)) CUBE_FAIL(CUBE_ERR_ARG, "cube_ext_finish: bad columns");
   const int total = B * L * P;
   hipLaunchKernelGGL(ext_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, ld_acc, B, L,
-                     root, P, (float)K, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
+                     root, P, (float)K, parts, part_stride, (uint16_t*)dst_a, (uint16_t*)dst_a_lo, ld_a, col_a, (uint16_t*)dst_b,
                      (uint16_t*)dst_b_lo, ld_b, col_b);
   CUBE_CHECK_LAUNCH("cube_ext_finish");
   return CUBE_OK;

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 12  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 13  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -39,6 +39,8 @@ class GemmArgs(ctypes.Structure):
         ("bias_tab", c_void_p), ("row_group", c_void_p), ("n_groups", c_int),
         ("groups", ctypes.POINTER(ConvGroups)),
         ("out0_int8", c_int),
+        ("batch", c_int), ("stride_A", ctypes.c_longlong), ("stride_W", ctypes.c_longlong), ("stride_bias", c_int),
+        ("stride_col0", c_int),
     ]
 
 
@@ -97,7 +99,7 @@ SIGNATURES = {
                                     c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,
                                           c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+    "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_split_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -194,11 +196,13 @@ def _planes(x, col=0):
 
 def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1, seq_len=0, n_valid=0, accumulate=0,
          rowmap=None, res=None, ld_res=0, res_mode=0, out1=None, ldo1=0, col1=0, out2=None, ldo2=0, col2=0,
-         a_col=0, bias_tab=None, row_group=None, groups=None, stream=None, w_scale=None, out0_int8=False):
+         a_col=0, bias_tab=None, row_group=None, groups=None, stream=None, w_scale=None, out0_int8=False,
+         batch=1, stride_a=0, stride_w=0, stride_bias=0, stride_col0=0):
     """A, W, out0 (bf16 epilogues), out1, out2: `Pair`s; out0 of CUBE_EPI_F32: an fp32 tensor.
     bf16x3 is used when both A and W carry a lo plane.  a_col: first column of A (bf16 elements).
     w_scale (f32 [N]): A, W and out0 are int8x2 planes (cube_gemm_i8x2; lda, Kc, ldo0 in int8 elements).
-    out0_int8: bf16 operands, but out0 receives the gate values as int8x2 planes (ldo0 in int8 elements)."""
+    out0_int8: bf16 operands, but out0 receives the gate values as int8x2 planes (ldo0 in int8 elements).
+    batch > 1: that many same-shape Linear problems in one launch (strides in elements, see include/cube_hip.h)."""
     a = GemmArgs()
     a.A, a.A_lo = _planes(A, a_col)
     a.W, a.W_lo = _planes(W)
@@ -223,6 +227,7 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     if groups is not None:
         a.groups = ctypes.pointer(groups)
     a.out0_int8 = 1 if out0_int8 else 0
+    a.batch, a.stride_A, a.stride_W, a.stride_bias, a.stride_col0 = batch, stride_a, stride_w, stride_bias, stride_col0
     if w_scale is not None:
         if a_col or col0:
             raise ValueError("int8x2 operands start at column 0")

@@ -243,6 +243,14 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
         h2 = pack_linear(sd["_ext_proj.%d._h2.linear_layer.weight" % i], sd["_ext_proj.%d._h2.linear_layer.bias" % i],
                          in_perm=np.concatenate([np.arange(hid), -np.ones(h1["N"] - hid, dtype=np.int64)]))
         pk["ext"].append(dict(h1=h1, h2=h2, E=e, Epad=p32(e)))
+    if len(ext_dims) > 1 and len(set(ext_dims)) == 1 and len({ek["h1"]["N"] for ek in pk["ext"]}) == 1:
+        # K LM layers of one width: their first (and their second) MLP layers as ONE batched launch each (cube_gemm_args.batch) -- stacked weights
+        from cube_amd.hip import Pair
+        for nm in ("h1", "h2"):  # (the second layers share one shape whenever the first ones do: hidden -> proj)
+            hs = [ek[nm] for ek in pk["ext"]]
+            pk["ext_%scat" % nm] = dict(W=Pair(torch.cat([h["W"].hi for h in hs], 0).contiguous(),
+                                               torch.cat([h["W"].lo for h in hs], 0).contiguous()),
+                                        bias=torch.cat([h["bias"] for h in hs]).contiguous(), K=hs[0]["K"], N=hs[0]["N"], n=len(hs))
     pk["word_emb"] = pack_table(sd["_word_emb.weight"])
     pk["lang_emb"] = pack_table(sd["_lang_emb.weight"])
     perm0 = lay.xw0_perm()

@@ -318,11 +318,22 @@ class _HipNet:
         offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in h["sizes"]])])
         bt = {n: ints[o:o + s] for n, o, s in zip(self._PART_NAMES, offs[:-1], h["sizes"])}
         embs = []
-        for e in h["embs"]:
+        # LM layers of one width land in ONE buffer [K, B*L, Epad] (constant stride: their MLPs' first layers are one
+        # batched launch, `_trunk`)
+        sizes = {e.size for e in h["embs"]}
+        whole = None
+        if len(h["embs"]) > 1 and len(sizes) == 1:
+            n1 = sizes.pop()
+            whole = hip.Pair(torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev),
+                             torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev) if self._split else None)
+        for k, e in enumerate(h["embs"]):
             src = torch.from_numpy(e).reshape(-1)
             x = src.to(dev, non_blocking=True)
-            pair = hip.Pair(torch.empty(x.numel(), dtype=torch.bfloat16, device=dev),
-                            torch.empty(x.numel(), dtype=torch.bfloat16, device=dev) if self._split else None)
+            if whole is not None:
+                pair = hip.Pair(whole.hi[k * n1:(k + 1) * n1], None if whole.lo is None else whole.lo[k * n1:(k + 1) * n1])
+            else:
+                pair = hip.Pair(torch.empty(x.numel(), dtype=torch.bfloat16, device=dev),
+                                torch.empty(x.numel(), dtype=torch.bfloat16, device=dev) if self._split else None)
             hip.check(lib.cube_split_f32(x.data_ptr(), x.numel(), pair.hi.data_ptr(), hip.ptr(pair.lo), hip.stream_handle()),
                       "cube_split_f32")
             embs.append(pair)
@@ -330,7 +341,7 @@ class _HipNet:
             ev = torch.cuda.Event()
             ev.record()
             self._staging_release(h["staging"], ev)
-        bt.update(B=h["B"], L=h["L"], T=h["T"], N=h["N"], W=h["W"], embs=embs, conv_groups=h["conv_groups"],
+        bt.update(B=h["B"], L=h["L"], T=h["T"], N=h["N"], W=h["W"], embs=embs, embs_whole=whole, conv_groups=h["conv_groups"],
                   char_rows=h["char_rows"], _keep=h.get("_groups_array"))
         if h.get("y_upos") is not None:
             bt["y_upos"] = h["y_upos"].to(dev).to(torch.int32).contiguous()
@@ -485,17 +496,31 @@ class _HipNet:
                  col0=lay.xw0_char, n_valid=ch, rowmap=bt["rowmap_word"], stream=st)
         gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138, tagger.py:111-119)
-        ext_h = buf.get("ext_h", BL, pk["ext"][0]["h1"]["N"])
-        ld_acc = 8 * ((P + 7) // 8)
+        cat = pk.get("ext_h1cat") if bt.get("embs_whole") is not None else None
+        n_ext, hn = len(pk["ext"]), pk["ext"][0]["h1"]["N"]
+        ext_h = buf.get("ext_h", BL, hn * (n_ext if cat else 1))
+        ld_part = 8 * ((P + 7) // 8)
+        parts = n_ext if cat else 1
+        ld_acc = ld_part * parts
         ext_acc = buf.get("ext_acc", BL, ld_acc, torch.float32)
-        for k, ek in enumerate(pk["ext"]):
-            h1, h2 = ek["h1"], ek["h2"]
-            hip.gemm(bt["embs"][k], ek["Epad"], BL, h1["K"], h1["W"], h1["N"], h1["bias"], hip.EPI_BF16_TANH,
-                     out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
-            hip.gemm(ext_h, h1["N"], BL, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
-                     n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
-        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, self._root, P, len(pk["ext"]), xw0.hi.data_ptr(),
-                                      lo(xw0.lo), lay.xw0_w, lay.xw0_ext,
+        if cat:  # the K first layers as one batched launch, side by side in ext_h; the K second layers as another,
+            # side by side in ext_acc; cube_ext_finish sums them in the order of the LM layers
+            ep, c2 = pk["ext"][0]["Epad"], pk["ext_h2cat"]
+            hip.gemm(bt["embs_whole"], ep, BL, cat["K"], cat["W"], cat["N"], cat["bias"], hip.EPI_BF16_TANH, out0=ext_h,
+                     ldo0=hn * n_ext, n_valid=hn, stream=st, batch=n_ext, stride_a=BL * ep, stride_w=cat["N"] * cat["K"],
+                     stride_bias=cat["N"], stride_col0=hn)
+            hip.gemm(ext_h, hn * n_ext, BL, c2["K"], c2["W"], c2["N"], c2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
+                     n_valid=P, stream=st, batch=n_ext, stride_a=hn, stride_w=c2["N"] * c2["K"], stride_bias=c2["N"],
+                     stride_col0=ld_part)
+        else:
+            for k, ek in enumerate(pk["ext"]):
+                h1, h2 = ek["h1"], ek["h2"]
+                hip.gemm(bt["embs"][k], ek["Epad"], BL, h1["K"], h1["W"], h1["N"], h1["bias"], hip.EPI_BF16_TANH,
+                         out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
+                hip.gemm(ext_h, h1["N"], BL, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
+                         n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
+        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, L, self._root, P, len(pk["ext"]), parts, ld_part,
+                                      xw0.hi.data_ptr(), lo(xw0.lo), lay.xw0_w, lay.xw0_ext,
                                       None if ext_b is None else ext_b.hi.data_ptr(),
                                       None if ext_b is None else lo(ext_b.lo), ext_b_w, ext_b_col, st), "cube_ext_finish")
         if self._root:

@@ -97,7 +97,7 @@ class Tokenizer(_HipNet):
                      out0=ext_h, ldo0=h1["N"], n_valid=h1["N"], stream=st)
             hip.gemm(ext_h, h1["N"], BT, h2["K"], h2["W"], h2["N"], h2["bias"], hip.EPI_F32, out0=ext_acc, ldo0=ld_acc,
                      n_valid=P, accumulate=1 if k > 0 else 0, stream=st)
-        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, T, 0, P, len(pk["ext"]), xw0.hi.data_ptr(), lo(xw0.lo),
+        hip.check(lib.cube_ext_finish(ext_acc.data_ptr(), ld_acc, B, T, 0, P, len(pk["ext"]), 1, 0, xw0.hi.data_ptr(), lo(xw0.lo),
                                       lay.xw0_w, 0, None, None, 0, 0, st), "cube_ext_finish")
         # gated Conv1d stack; every layer reads the running sum of the gates before it
         xa, xb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)

@@ -80,13 +80,17 @@ class TraceLib:
         M, N, Kc, taps = a.M, a.N, a.Kc, a.taps
         assert Kc % 32 == 0 and N % 128 == 0 and a.lda >= Kc and a.lda % 8 == 0
         assert taps == 1 or a.groups or (a.seq_len > 0 and M % a.seq_len == 0)
+        nbat = max(a.batch, 1)  # same-shape Linear problems in one launch
+        if nbat > 1:
+            assert taps == 1 and a.epilogue != hip.EPI_GATE and not a.rowmap and not a.groups and not a.accumulate
+            assert a.stride_A % 8 == 0 and a.stride_W % 8 == 0
         for nm, p in (("A", a.A), ("A_lo", a.A_lo)):
-            self._need("gemm " + nm, p, 2 * ((M - 1) * a.lda + Kc), 16)
+            self._need("gemm " + nm, p, 2 * ((nbat - 1) * a.stride_A + (M - 1) * a.lda + Kc), 16)
         for nm, p in (("W", a.W), ("W_lo", a.W_lo)):
-            self._need("gemm " + nm, p, 2 * N * taps * Kc, 16)
+            self._need("gemm " + nm, p, 2 * ((nbat - 1) * a.stride_W + N * taps * Kc), 16)
         gate = a.epilogue == hip.EPI_GATE
         nv = a.n_valid if a.n_valid > 0 else (N // 2 if gate else N)
-        self._need("gemm bias", a.bias, 4 * (N if gate else nv), 4)
+        self._need("gemm bias", a.bias, 4 * ((nbat - 1) * a.stride_bias + (N if gate else nv)), 4)
         out_rows, n_words = M, M
         if a.groups:
             cg = a.groups.contents
@@ -111,9 +115,10 @@ class TraceLib:
         if a.out0_int8:  # gate values as int8x2 planes for a next layer in cube_gemm_i8x2
             assert gate and a.res and a.res_mode in (0, 1, 2) and a.out0 and a.out0_lo
             esz = 1
-        assert a.ldo0 >= a.col0 + nv or not a.out0
+        last_col = a.col0 + (nbat - 1) * a.stride_col0
+        assert a.ldo0 >= last_col + nv or not a.out0
         for nm, p in (("out0", a.out0), ("out0_lo", a.out0_lo)):
-            self._need("gemm " + nm, p, esz * ((rows - 1) * a.ldo0 + a.col0 + nv), esz)
+            self._need("gemm " + nm, p, esz * ((rows - 1) * a.ldo0 + last_col + nv), esz)
         if gate:
             self._need("gemm res", a.res, 4 * ((M - 1) * a.ld_res + nv), 4)
             for nm, p, ld, c in (("out1", a.out1, a.ldo1, a.col1), ("out1_lo", a.out1_lo, a.ldo1, a.col1),
@@ -232,10 +237,12 @@ class TraceLib:
             self._need("conv0 " + nm, p, esz * ((total - 1) * ld_out + half), 8)
         return 0
 
-    def cube_ext_finish(self, acc, ld_acc, B, L, root, P, K, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b, stream):
+    def cube_ext_finish(self, acc, ld_acc, B, L, root, P, K, parts, part_stride, da, da_lo, ld_a, col_a, db, db_lo, ld_b, col_b,
+                        stream):
         self.calls.append(("ext_finish", B, L, P))
         assert P <= ld_acc and col_a + P <= ld_a and (db is None or col_b + P <= ld_b)
-        self._need("ext_finish acc", acc, 4 * ((B * L - 1) * ld_acc + P), 4)
+        assert parts >= 1 and (parts == 1 or (part_stride >= P and (parts - 1) * part_stride + P <= ld_acc))
+        self._need("ext_finish acc", acc, 4 * ((B * L - 1) * ld_acc + (parts - 1) * part_stride + P), 4)
         assert root in (0, 1)
         last = B * (L + root) - 1
         for nm, p, ld, c in (("a", da, ld_a, col_a), ("a_lo", da_lo, ld_a, col_a), ("b", db, ld_b, col_b),

@@ -98,6 +98,71 @@ def test_gemm_plain_epilogues(dev, M, seq, taps, Kc, N, epi, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("M,Kc,N,nb", [(333, 64, 128, 3), (8192, 768, 512, 4), (1000, 512, 128, 13)])
+def test_gemm_batched_linear_layers(dev, M, Kc, N, nb, split):
+    """cube_gemm_args.batch: nb Linear layers in one grid (operands at element strides, outputs side by side) give
+    bit for bit what nb launches give, in both layouts the parser uses (A as stacked planes -> bf16 tanh outputs;
+    A as column blocks of one plane -> f32 outputs)."""
+    from cube_amd import hip
+    g = torch.Generator().manual_seed(M + nb)
+    n_valid = N - 3
+    W = torch.randn((nb * N, Kc), generator=g) / np.sqrt(Kc)
+    bias = torch.randn(nb * N, generator=g)
+    A1 = torch.randn((nb * M, Kc), generator=g)          # stacked planes: problem z = rows [z*M, (z+1)*M)
+    A2 = torch.randn((M, nb * Kc), generator=g)          # column blocks:  problem z = columns [z*Kc, (z+1)*Kc)
+    if not split:
+        W, A1, A2 = _bf16_round(W), _bf16_round(A1), _bf16_round(A2)
+    Wd, bd = hip.Pair.split(W, split).to(dev), bias.to(dev)
+    A1d, A2d = hip.Pair.split(A1, split).to(dev), hip.Pair.split(A2, split).to(dev)
+
+    def pair(cols, fill):
+        return hip.Pair(torch.full((M, cols), fill, dtype=torch.bfloat16, device=dev),
+                        torch.full((M, cols), fill, dtype=torch.bfloat16, device=dev) if split else None)
+
+    def sub(pr, r0, r1):
+        return hip.Pair(pr.hi[r0:r1], None if pr.lo is None else pr.lo[r0:r1])
+    # layout 1
+    one, each = pair(nb * N, 7.0), pair(nb * N, 7.0)
+    hip.gemm(A1d, Kc, M, Kc, Wd, N, bd, hip.EPI_BF16_TANH, out0=one, ldo0=nb * N, n_valid=n_valid, batch=nb,
+             stride_a=M * Kc, stride_w=N * Kc, stride_bias=N, stride_col0=N)
+    for z in range(nb):
+        hip.gemm(sub(A1d, z * M, (z + 1) * M), Kc, M, Kc, sub(Wd, z * N, (z + 1) * N), N, bd[z * N:(z + 1) * N],
+                 hip.EPI_BF16_TANH, out0=each, ldo0=nb * N, col0=z * N, n_valid=n_valid)
+    torch.cuda.synchronize()
+    assert torch.equal(one.hi.view(torch.int16), each.hi.view(torch.int16))
+    if split:
+        assert torch.equal(one.lo.view(torch.int16), each.lo.view(torch.int16))
+    got = one.float().cpu().view(M, nb, N)
+    ref = torch.tanh(torch.einsum("zmk,znk->mzn", A1.double().view(nb, M, Kc), W.double().view(nb, N, Kc))
+                     + bias.double().view(nb, N)).float()
+    tol = 3e-5 if split else 1e-2
+    np.testing.assert_allclose(got[:, :, :n_valid].numpy(), ref[:, :, :n_valid].numpy(), rtol=tol, atol=tol)
+    for pl in [one.hi] + ([one.lo] if split else []):  # nothing outside the valid columns
+        assert (pl.float().cpu().view(M, nb, N)[:, :, n_valid:] == 7.0).all()
+    # layout 2
+    one = torch.full((M, nb * N), 7.0, dtype=torch.float32, device=dev)
+    each = torch.full((M, nb * N), 7.0, dtype=torch.float32, device=dev)
+    hip.gemm(A2d, nb * Kc, M, Kc, Wd, N, bd, hip.EPI_F32, out0=one, ldo0=nb * N, n_valid=n_valid, batch=nb,
+             stride_a=Kc, stride_w=N * Kc, stride_bias=N, stride_col0=N)
+    for z in range(nb):
+        hip.gemm(A2d, nb * Kc, M, Kc, sub(Wd, z * N, (z + 1) * N), N, bd[z * N:(z + 1) * N], hip.EPI_F32, out0=each,
+                 ldo0=nb * N, col0=z * N, n_valid=n_valid, a_col=z * Kc)
+    torch.cuda.synchronize()
+    assert torch.equal(one, each)
+    ref = (torch.einsum("mzk,znk->mzn", A2.double().view(M, nb, Kc), W.double().view(nb, N, Kc)) + bias.double().view(nb, N)).float()
+    got = one.cpu().view(M, nb, N)
+    np.testing.assert_allclose(got[:, :, :n_valid].numpy(), ref[:, :, :n_valid].numpy(), rtol=3e-5, atol=3e-5)
+    assert (got[:, :, n_valid:] == 7.0).all()
+    # what a batch cannot be combined with is refused
+    with pytest.raises(RuntimeError, match="batch"):
+        hip.gemm(A2d, nb * Kc, M, Kc, Wd, N, bd, hip.EPI_F32, out0=one, ldo0=nb * N, n_valid=n_valid, batch=nb, stride_a=Kc,
+                 stride_w=N * Kc, stride_bias=N, stride_col0=N, accumulate=1)
+    with pytest.raises(RuntimeError, match="ldo0"):
+        hip.gemm(A2d, nb * Kc, M, Kc, Wd, N, bd, hip.EPI_F32, out0=one, ldo0=nb * N, n_valid=n_valid, batch=nb + 1, stride_a=Kc,
+                 stride_w=N * Kc, stride_bias=N, stride_col0=N)
+
+
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("M,seq,Kc,half", [(6 * 11, 11, 64, 80), (11 * 2400, 11, 64, 256),  # small / 256x256 tiles
                                            (11 * 700, 11, 96, 256)])  # 160-row tiles, three weight stages
 def test_gemm_gate_epilogue_and_rowmap(dev, split, M, seq, Kc, half):

@@ -214,7 +214,8 @@ def test_abi_rejects_bad_arguments():
     assert "workspace too small" in err(lib.cube_mst_decode(P, P, 4, 16, P, P, P, 16, None))
     assert lib.cube_mst_workspace_bytes(4, 200) > lib.cube_mst_workspace_bytes(4, 100) > 0
     assert "D/columns" in err(lib.cube_label_score(P, None, 448, 224, 288, P, None, P, 10, P, P, 2, 3, P, P, None))
-    assert "bad args" in err(lib.cube_ext_finish(P, 8, 2, 3, 2, 2, 1, P, None, 64, 0, None, None, 0, 0, None))  # root = 2
+    assert "bad args" in err(lib.cube_ext_finish(P, 8, 2, 3, 2, 2, 1, 1, 0, P, None, 64, 0, None, None, 0, 0, None))  # root = 2
+    assert "parts" in err(lib.cube_ext_finish(P, 8, 2, 3, 1, 2, 3, 3, 4, P, None, 64, 0, None, None, 0, 0, None))  # 3 parts, rows of 8
 
 
 def test_host_helper_matches_numpy_collate(monkeypatch):
