@@ -124,7 +124,7 @@ def test_forward_matches_reference_golden(dev, g9, tag, dk, n):
     nstep = min(16, ref_c.shape[1])
     for t in range(nstep):
         agree = (got_c[:, :t] == ref_c[:, :t]).all(axis=1)
-        assert agree.mean() > 0.9
+        assert agree.mean() >= 0.99  # measured: no word leaves the reference's history before step 20
         d = np.abs(yc[agree, t] - l16[agree, t]).max() / np.abs(l16[agree, t]).max()
         assert d < REL_TOL, (t, d)
         d = np.abs(yk[agree, t] - k16[agree, t]).max() / max(np.abs(k16[agree, t]).max(), 1e-6)
@@ -135,7 +135,7 @@ def test_forward_matches_reference_golden(dev, g9, tag, dk, n):
     assert np.array_equal(oc_all.argmax(-1), ref_c) or tag == "small"
     # (the small model is close to chaotic: the fp32 and fp64 oracles already part after ~200 steps in 2 of
     # 128 words, at margins of 3e-3 .. 6e-2, so its margin rule covers the first 64 steps only)
-    nbad = _compare_sequences(got_c, got_k, ref_c, ref_k, oc_all, max_bad_frac=0.05 if tag == "full" else 0.10,
+    nbad = _compare_sequences(got_c, got_k, ref_c, ref_k, oc_all, max_bad_frac=0.04 if tag == "full" else 0.07,  # measured: 1/37, 4/128; 1/37, 7/128
                               margin_steps=1 << 30 if tag == "full" else 64)
     print("%s/%s: %d of %d words differ from the reference (near-ties)" % (tag, dk, nbad, len(ref_c)))
 
@@ -156,7 +156,7 @@ def test_process_matches_reference_golden(dev, golden_dir, tag, bs):
     # words that run into the 20*S failsafe accumulate bf16x3 rounding over hundreds of fed-back steps
     # and may leave the reference's limit cycle at a near-tie (see test_forward_matches_reference_golden)
     print("%s bs%d: %d of %d lemmas differ" % (tag, bs, bad, len(ref)))
-    assert bad <= (0.02 if tag == "full" else 0.05) * len(ref), bad
+    assert bad <= (0.01 if tag == "full" else 0.025) * len(ref), bad  # measured: 3 / 3 / 7 of 384
 
 
 def test_bf16_single_pass_mode_runs_and_mostly_agrees(dev, g9):
