@@ -543,7 +543,7 @@ def test_forward_api_outputs(dev, golden_dir):
 @pytest.mark.parametrize("bs", [4, 32])
 def test_process_document_text_matches_reference(dev, golden_dir, tag, case, bs):
     """Parser.process end to end against the REFERENCE's CoNLL-U text (golden G6, both batch
-    sizes: results depend on batch composition): >= 99.9 % of the lines identical."""
+    sizes: results depend on batch composition): identical text."""
     from cube_amd.networks.utils import MorphoCollate
     p, cfg, enc, sd = _model(dev, case, "bf16x3")
     doc = cases.document(case, enc, "g6")
@@ -553,7 +553,8 @@ def test_process_document_text_matches_reference(dev, golden_dir, tag, case, bs)
     got = str(doc).split("\n")
     assert len(got) == len(exp)
     diff = sum(x != y for x, y in zip(got, exp))
-    assert diff <= len(got) // 1000, diff
+    print("process %s bs%d: %d of %d lines differ" % (tag, bs, diff, len(got)))
+    assert diff == 0, diff  # measured: identical in all four cases
 
 
 # ------------------------------------------------------------------------------------------
@@ -613,7 +614,8 @@ def test_tagger_process_text_matches_reference(dev, golden_dir, tag, case, bs):
     got = str(doc).split("\n")
     assert len(got) == len(exp)
     diff = sum(x != y for x, y in zip(got, exp))
-    assert diff <= len(got) // 1000, diff
+    print("process %s bs%d: %d of %d lines differ" % (tag, bs, diff, len(got)))
+    assert diff == 0, diff  # measured: identical in all four cases
 
 
 def test_tagger_process_needs_a_flag(dev):
@@ -706,7 +708,8 @@ def test_process_edge_documents(dev):
         got, exp = str(doc).split("\n"), str(ref).split("\n")
         assert len(got) == len(exp)
         diff = sum(x != y for x, y in zip(got, exp))
-        assert diff <= max(1, len(got) // 100), (diff, len(got))  # random-init margins: allow a near-tie flip
+        print("edge documents %s: %d of %d lines differ" % (lens[:3], diff, len(got)))
+        assert diff == 0, (diff, len(got))  # measured: identical text (a near-tie flip here would need its margin shown)
 
 
 def test_process_bucketed_writes_back_in_place(dev):
