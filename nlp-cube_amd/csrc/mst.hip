@@ -11,7 +11,11 @@
 //                      or appends one task per candidate root to a device-side task list.
 //   mst_root_kernel    one wave per (sentence, candidate root): the reference's `set_root` +
 //                      CLE + log-probability score.  Grid-strides over the device-side task
-//                      count: no host round trip.
+//                      count: no host round trip.  Two launches: the first runs, per sentence, the
+//                      candidate with the largest score BOUND (every word takes its best head; or all
+//                      candidates when there are at most MST_BOUND_MIN_CAND), the second the other
+//                      candidates whose bound is not below that tree's exact score.  The skipped ones
+//                      cannot be the reference's maximum, so the chosen heads are unchanged.
 //   mst_select_kernel  first strictly-best candidate per sentence (utils.py:548-555), or
 //                      status 1 when every candidate scores -inf (the reference asserts).
 //
@@ -40,6 +44,7 @@ namespace {
 // tile until they are done.  Packed, the same tasks sit on B / 14 CUs (L = 32) and leave the rest of the chip alone.
 constexpr int MST_MAX_WAVES = 16;
 constexpr int MST_ROOT_MAX_BLOCKS = 96;  // CUs the rooted re-runs may spread over when tasks are packed
+constexpr int MST_BOUND_MIN_CAND = 4;    // up to this many candidate roots of a sentence all run in the first round (mst_first_kernel)
 
 constexpr int MST_MAX_N = 130;   // L <= 129: S (n*n fp64) + records fit the 160 KiB LDS of one CU
 constexpr int MST_MAX_N_GLOBAL = 255;  // longer sentences, node ids still bytes: S lives in the workspace (HBM/L2), slow but exact
@@ -476,6 +481,9 @@ struct MstWs {
   int32_t* task_sent;   // [B*L]
   int32_t* task_root;   // [B*L]
   double* task_score;   // [B*L]
+  double* task_ub;      // [B*L] upper bound of the task's tree score (see mst_first_kernel)
+  int32_t* sent_top;    // [B] the task with the largest bound of the sentence: runs first (-1: all of its tasks do)
+  int32_t* top_list;    // [B*L] the tasks of the first round, compacted (count in ntasks[1])
   void* task_tree;      // [B*L][L+1] node ids (1 or 2 bytes each)
   double* s_first;      // long-sentence mode only: [B][n_max * ld] score matrices of the first pass
   double* s_root;       // and [mst_root_blocks][n_max * ld] of the root pass
@@ -499,7 +507,7 @@ __host__ __device__ inline size_t mst_rec_stride(int T, int id) { return align16
 __host__ inline size_t mst_ws_bytes(int B, int L) {
   const size_t nt = (size_t)B * L;
   const int id = mst_id_bytes(L);
-  size_t b = 16 + align16(4 * (size_t)B) * 2 + align16(4 * nt) * 2 + align16(8 * nt) + align16(nt * (L + 1) * id);
+  size_t b = 16 + align16(4 * (size_t)B) * 3 + align16(4 * nt) * 3 + align16(8 * nt) * 2 + align16(nt * (L + 1) * id);
   if (L + 1 > MST_MAX_N) b += 8 * mst_s_elems(L) * (size_t)B;
   if (L + 1 >= MST_ROOT_GLOBAL_N) b += 8 * mst_s_elems(L) * mst_root_blocks(B, L);
   if (id == 2) b += mst_rec_stride(L + 1, 2) * (size_t)B;
@@ -516,6 +524,9 @@ __host__ inline MstWs mst_ws_carve(void* ws, int B, int L) {
   w.task_sent = (int32_t*)q; q += align16(4 * nt);
   w.task_root = (int32_t*)q; q += align16(4 * nt);
   w.task_score = (double*)q; q += align16(8 * nt);
+  w.task_ub = (double*)q; q += align16(8 * nt);
+  w.sent_top = (int32_t*)q; q += align16(4 * (size_t)B);
+  w.top_list = (int32_t*)q; q += align16(4 * nt);
   w.task_tree = (void*)q; q += align16(nt * (L + 1) * mst_id_bytes(L));
   w.s_first = (double*)q;
   w.s_root = w.s_first + (L + 1 > MST_MAX_N ? mst_s_elems(L) * B : 0);
@@ -602,7 +613,41 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
     status[b] = -1;
   }
   base_task = __shfl(base_task, 0);
+  // Upper bounds of the candidates' tree scores (no counterpart in the reference, which runs every candidate): in the
+  // tree rooted in r every other word k takes a head j >= 1, j != k, so its log-score is at most
+  //   ub_r = sum_{k != r} log max_j p[k][j]  +  log p[r][0].
+  // The root kernel runs the candidate with the largest bound first and skips every candidate whose bound is below that
+  // tree's exact score: it cannot be the reference's (strict, first) maximum.  Rows without a positive finite maximum or
+  // a NaN anywhere switch the bounds off (+inf: every candidate runs).
+  // Sentences with few candidates run them all in the first round: a second round costs a task's latency.
+  const bool two_rounds = ncand > MST_BOUND_MIN_CAND;
+  bool bound_ok = !has_nan && two_rounds;
+  double tot = 0.0;
+  if (bound_ok) {
+    for (int k = 1 + lane; k < n; k += 64) {  // a row per lane, eight loads in flight
+      const float* row = p + (size_t)(k - 1) * T;
+      float best = -1.f;
+      for (int j0 = 1; j0 < n; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j0 + u < n && j0 + u != k) ? row[j0 + u] : -1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) best = fmaxf(best, v[u]);
+      }
+      const double mk = (double)best;
+      if (!(mk > 0.0) || mk > 1.0e300) bound_ok = false;
+      const double lg = log(mk > 0.0 ? mk : 1.0);
+      m.hval[k] = lg;
+      tot += lg;
+    }
+    bound_ok = (__ballot(!bound_ok) == 0ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    MST_SYNC();
+  }
   int run = 0;
+  double top_ub = -INFINITY;
+  int top_t = 0x7fffffff;
   for (int base = 0; base < n; base += 64) {
     const int k = base + lane;
     const bool ok = (k < n) && m.flag[k];
@@ -612,24 +657,63 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
       const int t = base_task + run + __popcll(bm & below);
       ws.task_sent[t] = b;
       ws.task_root[t] = k;
+      double ub = INFINITY;
+      if (bound_ok) {
+        ub = (tot - m.hval[k]) + log((double)p[(size_t)(k - 1) * T]);
+        if (ub != ub) ub = INFINITY;
+      }
+      ws.task_ub[t] = ub;
+      if (top_t == 0x7fffffff || ub > top_ub) { top_ub = ub; top_t = t; }  // (t grows with the loop: the first maximum)
     }
     run += __popcll(bm);
+  }
+  if (!two_rounds) {
+    int slot0 = 0;
+    if (lane == 0) {
+      ws.sent_top[b] = -1;
+      slot0 = atomicAdd(ws.ntasks + 1, ncand);
+    }
+    slot0 = __shfl(slot0, 0);
+    for (int i = lane; i < ncand; i += 64) ws.top_list[slot0 + i] = base_task + i;
+    return;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // the largest bound, the smallest task among equals
+    const double ou = __shfl_xor(top_ub, o);
+    const int ot = __shfl_xor(top_t, o);
+    if (ot != 0x7fffffff && (top_t == 0x7fffffff || ou > top_ub || (ou == top_ub && ot < top_t))) { top_ub = ou; top_t = ot; }
+  }
+  if (lane == 0) {
+    ws.sent_top[b] = top_t;
+    ws.top_list[atomicAdd(ws.ntasks + 1, 1)] = top_t;
   }
 }
 
 template <bool GS, typename IdT, bool GREC>
 __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
                                                                       const int32_t* __restrict__ lens, int B, int L, MstWs ws,
-                                                                      int lds_task) {
+                                                                      int lds_task, int phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   unsigned char* const smem = smem_all + (size_t)wave * lds_task;
   const int lane = threadIdx.x & 63;
   const int T = L + 1;
-  const int ntasks = min(*ws.ntasks, B * L);
-  for (int t = blockIdx.x * wpb + wave; t < ntasks; t += gridDim.x * wpb) {
+  // phase 0: the candidate with the largest bound of every sentence; phase 1 (a launch of its own, after it): the others,
+  // except those whose bound is below the exact score phase 0 found (margin: the rounding of the two log-sums, ~1e-13)
+  const int ntasks = min(ws.ntasks[phase == 0 ? 1 : 0], B * L);
+  for (int ti = blockIdx.x * wpb + wave; ti < ntasks; ti += gridDim.x * wpb) {
     MST_SYNC();
+    const int t = phase == 0 ? ws.top_list[ti] : ti;
     const int b = ws.task_sent[t];
+    if (phase != 0) {
+      const int top = ws.sent_top[b];
+      if (top < 0 || t == top) continue;
+      const double lb = ws.task_score[top];
+      if (ws.task_ub[t] < lb - 1e-9 * (1.0 + fabs(lb))) {
+        if (lane == 0) ws.task_score[t] = -INFINITY;
+        continue;
+      }
+    }
     const int root = ws.task_root[t];
     const int n = min(max(lens[b], 0), L) + 1;
     const float* p = probs + (size_t)b * L * T;
@@ -731,8 +815,13 @@ int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* h
     const int cap = w_root > 1 ? MST_ROOT_MAX_BLOCKS : 4096;
     if (nblk > cap) nblk = cap;
   }
+  int nblk0 = (MST_BOUND_MIN_CAND * B + w_root - 1) / w_root;  // one task per sentence, or its few candidates
+  if (nblk0 > nblk) nblk0 = nblk;
+  hipLaunchKernelGGL((mst_root_kernel<GS_ROOT, IdT, GREC_ROOT>), dim3(nblk0), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws,
+                     (int)task_root, 0);
+  CUBE_CHECK_LAUNCH("cube_mst_decode(root, first candidates)");
   hipLaunchKernelGGL((mst_root_kernel<GS_ROOT, IdT, GREC_ROOT>), dim3(nblk), dim3(64 * w_root), lds_root, st, probs, lens, B, L, ws,
-                     (int)task_root);
+                     (int)task_root, 1);
   CUBE_CHECK_LAUNCH("cube_mst_decode(root)");
   hipLaunchKernelGGL(mst_select_kernel<IdT>, dim3(B), dim3(64), 0, st, lens, B, L, heads, status, ws);
   CUBE_CHECK_LAUNCH("cube_mst_decode(select)");

@@ -311,7 +311,7 @@ class TraceLib:
         idb = 2 if n > 255 else 1  # bytes per node id
         s_bytes, rec_bytes = 8 * n * (n | 1), a16(idb * (n * n + 3 * n + 16))
         root_blocks = min(nt, 3072 if idb == 1 else max(8, min(3072, (2 << 30) // (s_bytes + 2 * (n * n + 3 * n + 16)))))
-        b = 16 + 2 * a16(4 * B) + 2 * a16(4 * nt) + a16(8 * nt) + a16(nt * n * idb)
+        b = 16 + 3 * a16(4 * B) + 3 * a16(4 * nt) + 2 * a16(8 * nt) + a16(nt * n * idb)  # + bounds, first-candidate lists
         if n > 130:  # long-sentence mode: score matrices of the first pass in the workspace
             b += s_bytes * B
         if n >= 96:  # the rooted re-runs keep theirs there from 96 nodes on (one per workgroup), and their records

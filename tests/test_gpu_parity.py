@@ -383,6 +383,45 @@ def test_mst_ties_and_zeros_match_oracle(dev):
     assert n_checked >= 20 and n_near_ties <= 3
 
 
+def test_mst_many_root_candidates_match_oracle(dev):
+    """Sentences whose first tree has no root or many (near-uniform probabilities, as random-init weights give; a root
+    column that is small, large, or tied): the kernel runs the candidate with the largest score bound first and skips
+    the candidates whose bound is below that tree's exact score -- the chosen heads must stay the reference's."""
+    from oracle import cle_oracle
+    from cube_amd.networks.utils import ChuLiuEdmondsDecoder
+    dec = ChuLiuEdmondsDecoder(dev)
+    rng = np.random.default_rng(77)
+    n_multi = n_checked = n_near_ties = 0
+    for L, B, sigma, root_shift, quant in ((12, 24, 0.02, 0.0, 0), (32, 24, 0.02, 0.0, 0), (32, 16, 0.3, 0.5, 0),
+                                           (60, 8, 0.05, 0.05, 0), (100, 4, 0.02, 0.03, 0), (128, 3, 0.1, 0.3, 0), (32, 16, 0.02, 0.02, 0), (64, 6, 0.01, 0.012, 0),
+                                           (24, 16, 0.5, 0.0, 16), (40, 8, 0.2, 0.2, 64)):
+        g = rng.normal(size=(B, L, L + 1)) * sigma
+        g[:, :, 0] += root_shift
+        probs = _softmax_np(g)
+        if quant:  # equal entries: equal bounds and equal tree scores among the candidates
+            probs = (np.maximum(np.round(probs * quant * (L + 1)), 1.0) / (quant * (L + 1) * 2)).astype(np.float32)
+        lens = np.array([L] + [int(rng.integers(2, L + 1)) for _ in range(B - 1)], dtype=np.int64)
+        heads, status = dec.decode_device(torch.from_numpy(probs).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev))
+        heads, status = heads.cpu().numpy(), status.cpu().numpy()
+        for b in range(B):
+            n = int(lens[b]) + 1
+            sm = np.zeros((n, n))
+            sm[1:, :] = probs[b, :n - 1, :n]
+            sm *= (1 - np.eye(n))
+            n_multi += not cle_oracle.root_candidates(sm, cle_oracle.chuliu_edmonds(sm.copy()))[1]
+            exp = cle_oracle.decode(probs[b:b + 1], lens[b:b + 1])[0]
+            assert status[b] == 0, "L=%d b=%d" % (L, b)
+            got = heads[b, :lens[b]]
+            if not np.array_equal(got, exp):
+                rows = np.arange(lens[b])
+                sc_got, sc_exp = (np.log(probs[b][rows, h].astype(np.float64)).sum() for h in (got, exp))
+                assert quant and (got == 0).sum() == 1 and abs(sc_got - sc_exp) <= 1e-12 * abs(sc_exp), "L=%d b=%d" % (L, b)
+                n_near_ties += 1
+            n_checked += 1
+    print("%d sentences, %d with a rooted second pass, %d last-bit ties" % (n_checked, n_multi, n_near_ties))
+    assert n_multi >= 30 and n_near_ties <= 3
+
+
 # ------------------------------------------------------------------------------------------
 # whole path: bf16x3 against the REFERENCE's outputs (golden) and the fp32 oracle;
 #             bf16 (single pass) against the bf16-contract oracle
