@@ -313,6 +313,9 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
   int have_ibuf = 0;
   WordLayout wl;
   wl.tp = NULL;
+  EmbJob jobs[16 * 64];     /* the embedding copies run on worker threads beside the index-array pass */
+  pthread_t th[16 * 64];
+  int n_started = 0;
 
   Py_ssize_t E[64], Epad[64];
   if (PyObject_GetBuffer(ints_out, &ibuf, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) goto fail;
@@ -482,6 +485,29 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
   cp_off[N] = (int32_t)total_chars;
 
   g_t[1] += now_s() - t_start; t_start = now_s();
+  /* ---- external embeddings -> padded [B*L, Epad] rows: worker threads, started here and joined at the end, so that
+   * the copies (memory-bound) run beside the index-array pass below.  The GIL stays held all the while: the vectors
+   * are borrowed, and nothing else of this process's Python may run meanwhile. */
+  if (K > 0) {
+    int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    const Py_ssize_t rows = B * L;
+    const int small = rows * Epad[0] < (1 << 16); /* a thread costs more than such a copy */
+    if (small) nt = 1;
+    int nj = 0;
+    for (Py_ssize_t k = 0; k < K && nj < 16 * 64; ++k)
+      for (int t = 0; t < nt && nj < 16 * 64; ++t) {
+        EmbJob* j = &jobs[nj++];
+        j->src = esrc + (size_t)k * B * L;
+        j->dst = (float*)ebuf[k].buf;
+        j->E = E[k];
+        j->Epad = Epad[k];
+        j->row0 = rows * t / nt;
+        j->row1 = rows * (t + 1) / nt;
+      }
+    for (; !small && n_started < nj; ++n_started)
+      if (pthread_create(&th[n_started], NULL, emb_worker, &jobs[n_started]) != 0) break;
+    for (int t = n_started; t < nj; ++t) emb_worker(&jobs[t]); /* (no thread to be had: the caller's thread copies) */
+  }
   /* ---- characters: code point -> (char id, case id); unknown code points go back to the caller */
   {
     int32_t* cps = (int32_t*)sc_alloc(14, sizeof(int32_t) * (size_t)(total_chars + 1), 0);
@@ -613,36 +639,9 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     }
 
     g_t[2] += now_s() - t_start; t_start = now_s();
-    /* ---- external embeddings -> padded [B*L, Epad] rows, on worker threads */
-    if (K > 0) {
-      int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
-      const Py_ssize_t rows = B * L;
-      if (rows * Epad[0] < (1 << 16)) nt = 1;
-      EmbJob jobs[16 * 64];
-      pthread_t th[16 * 64];
-      int nj = 0;
-      for (Py_ssize_t k = 0; k < K; ++k)
-        for (int t = 0; t < nt; ++t) {
-          EmbJob* j = &jobs[nj++];
-          j->src = esrc + (size_t)k * B * L;
-          j->dst = (float*)ebuf[k].buf;
-          j->E = E[k];
-          j->Epad = Epad[k];
-          j->row0 = rows * t / nt;
-          j->row1 = rows * (t + 1) / nt;
-          if (nj >= 16 * 64) break;
-        }
-      /* the GIL stays held: the vectors are borrowed, and nothing else of this process's Python may run meanwhile */
-      if (nj == 1) {
-        emb_worker(&jobs[0]);
-      } else {
-        int started = 0;
-        for (; started < nj - 1; ++started)
-          if (pthread_create(&th[started], NULL, emb_worker, &jobs[started]) != 0) break;
-        for (int t = started; t < nj; ++t) emb_worker(&jobs[t]); /* the caller's thread takes the rest */
-        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-      }
-    }
+    /* the embedding copies started above: what is left of them after the index arrays */
+    for (int t = 0; t < n_started; ++t) pthread_join(th[t], NULL);
+    n_started = 0;
 
     g_t[3] += now_s() - t_start; t_start = now_s();
     ++g_calls;
@@ -658,6 +657,7 @@ fail:
   Py_XDECREF(missing);
   result = NULL;
 done:
+  for (int t = 0; t < n_started; ++t) pthread_join(th[t], NULL); /* (early exits: the copies write into ebuf) */
   if (have_ibuf) PyBuffer_Release(&ibuf);
   for (Py_ssize_t k = 0; k < n_ebuf; ++k) PyBuffer_Release(&ebuf[k]);
   if (wemb) for (Py_ssize_t w = 0; w < n_wemb; ++w) Py_XDECREF(wemb[w]);
@@ -735,6 +735,22 @@ static PyObject* timing(PyObject* self, PyObject* args) {
   return r;
 }
 
+/* max_words(sentences) -> the longest sentence's word count (L of a batch), without a Python-level loop */
+static PyObject* max_words(PyObject* self, PyObject* args) {
+  PyObject* sents;
+  if (!PyArg_ParseTuple(args, "O!", &PyList_Type, &sents)) return NULL;
+  Py_ssize_t mx = 0;
+  for (Py_ssize_t b = 0; b < PyList_GET_SIZE(sents); ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws) return NULL;
+    const Py_ssize_t m = PyObject_Length(ws);
+    Py_DECREF(ws);
+    if (m < 0) return NULL;
+    if (m > mx) mx = m;
+  }
+  return PyLong_FromSsize_t(mx);
+}
+
 /* geometry(sentences) -> (int32 [n] words per sentence, int32 [n] longest word per sentence): what decides the
  * padding of a reference batch (longest sentence, longest word), for merging reference batches of equal geometry
  * (cube_amd/sharding.py) without a Python-level pass over every word. */
@@ -761,6 +777,7 @@ static PyObject* geometry(PyObject* self, PyObject* args) {
     pl[b] = (int32_t)m;
     Py_ssize_t mx = 0;
     for (Py_ssize_t j = 0; j < m; ++j) {
+      if (j + 8 < m) __builtin_prefetch(PyList_GET_ITEM(ws, j + 8));
       PyObject* t = word_get(PyList_GET_ITEM(ws, j), &wl, F_WORD);
       if (!t || !PyUnicode_Check(t) || PyUnicode_READY(t) != 0) {
         if (t) PyErr_SetString(PyExc_TypeError, "geometry: word.word is not a str");
@@ -845,6 +862,7 @@ static PyMethodDef methods[] = {
     {"write_back_flat", write_back_flat, METH_VARARGS, "result ids [n_words, 5] -> the words, in order"},
     {"timing", timing, METH_NOARGS, "accumulated seconds per stage of featurize since the last call"},
     {"geometry", geometry, METH_VARARGS, "words per sentence and longest word per sentence"},
+    {"max_words", max_words, METH_VARARGS, "word count of the longest sentence"},
     {"write_back", write_back, METH_VARARGS, "result ids -> head / label / upos / xpos / attrs of every word"},
     {NULL, NULL, 0, NULL}};
 

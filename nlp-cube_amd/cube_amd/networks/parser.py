@@ -234,7 +234,7 @@ class _HipNet:
         if hm is None or not isinstance(collate, MorphoCollate) or not isinstance(batch, list) or not batch:
             return None
         B = len(batch)
-        L = max(len(s.words) for s in batch)
+        L = hm.max_words(batch) if hasattr(hm, "max_words") else max(len(s.words) for s in batch)
         if L < 1:
             return None
         pk = self._pk_cpu
