@@ -160,14 +160,19 @@ def end_to_end(p, enc, docs, n_target=8192):
     """Secondary number: `Parser.process(Document)` from Sentence objects to filled words — C
     featurisation, upload, the device pipeline, write-back — at batch_size 256 and at the reference's default 4
     (reference batches of equal padding geometry merged into device batches, results unchanged)."""
-    import copy
+    from cube_amd import synth
     from cube_amd.io_utils.objects import Document
     from cube_amd.networks.utils import MorphoCollate
     col = MorphoCollate(enc)
     doc = Document()
-    while len(doc.sentences) < n_target:  # separate objects and embedding vectors per copy, as a real document has
-        for d in docs:
-            doc.sentences.extend(copy.deepcopy(d).sentences)
+    ext = tuple(e.shape[0] for e in docs[0].sentences[0].words[0].emb)
+    L = len(docs[0].sentences[0].words)
+    i = 0
+    while len(doc.sentences) < n_target:
+        # fresh sentences, not copies of the bench batches: repeated sentences would let `Parser.dedup_words` skip most
+        # of the character CNN, which a real document does not offer to that extent
+        doc.sentences.extend(synth.make_document(enc, [L] * 256, seed=500000 + i, ext_word_emb=ext).sentences)
+        i += 1
     out = {}
     for bs in (256, 4):
         p.process(doc, col, batch_size=bs)

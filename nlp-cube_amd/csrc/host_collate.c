@@ -212,7 +212,7 @@ static inline double now_s(void) {
 
 /* Grow-only scratch buffers of featurize.  The call holds the GIL from start to end, so it cannot overlap itself;
  * keeping the buffers avoids a dozen malloc / mmap / page-fault / munmap rounds of 64..800 KB per batch. */
-enum { SC_SLOTS = 16 };
+enum { SC_SLOTS = 18 };
 static void* g_sc[SC_SLOTS];
 static size_t g_sc_cap[SC_SLOTS];
 static void* sc_alloc(int slot, size_t bytes, int zero) {
@@ -270,19 +270,22 @@ static void* emb_worker(void* arg) {
  *   emb_out   : tuple of K writable float32 buffers of >= B*L*Epad_k elements;  emb_dims: tuple of (E_k, Epad_k)
  *   groups_addr: address of n_layers cube_conv_groups structs (ctypes array), filled here
  *   ints_out  : writable int32 buffer that receives the packed index arrays
- * -> (int32 elements written to ints_out, sizes tuple of 10 ints, N, W, rows tuple of n_layers+1 ints)
+ *   dedup     : (optional) 1 = words of the batch with the same spelling and language go through the character CNN
+ *               once: the per-word arrays then hold the N_u distinct words, and two more arrays list, for every
+ *               repeated word, its row of the word-level input and the row of the first occurrence to copy from
+ * -> (int32 elements written to ints_out, sizes tuple of 10 (dedup: 12) ints, N (dedup: N_u), W, rows tuple of n_layers+1 ints)
  *    or a list of code points missing from cp_tab (the caller extends the table and calls again)
  *    or an int: the number of int32 elements ints_out must hold (it was too small; the caller calls again). */
 static PyObject* featurize(PyObject* self, PyObject* args) {
   PyObject *sents, *word2int, *wid_cache, *emb_out, *emb_dims, *ints_out;
   PyArrayObject* cp_tab;
   long unk;
-  int root, n_layers, n_case, n_threads;
+  int root, n_layers, n_case, n_threads, dedup = 0;
   Py_ssize_t L;
   unsigned long long groups_addr;
-  if (!PyArg_ParseTuple(args, "O!O!O!lO!iiinO!O!KiO", &PyList_Type, &sents, &PyDict_Type, &word2int, &PyDict_Type, &wid_cache,
+  if (!PyArg_ParseTuple(args, "O!O!O!lO!iiinO!O!KiO|i", &PyList_Type, &sents, &PyDict_Type, &word2int, &PyDict_Type, &wid_cache,
                         &unk, &PyArray_Type, &cp_tab, &root, &n_layers, &n_case, &L, &PyTuple_Type, &emb_out,
-                        &PyTuple_Type, &emb_dims, &groups_addr, &n_threads, &ints_out))
+                        &PyTuple_Type, &emb_dims, &groups_addr, &n_threads, &ints_out, &dedup))
     return NULL;
   if (PyArray_TYPE(cp_tab) != NPY_INT32 || PyArray_NDIM(cp_tab) != 2 || PyArray_DIM(cp_tab, 0) != 2 ||
       !PyArray_IS_C_CONTIGUOUS(cp_tab)) {
@@ -533,10 +536,44 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       goto done;
     }
 
+    /* ---- repeated words: rep[w] = the first word of the batch with the same code points and language (itself if
+     * there is none).  The character CNN's output for a word depends on nothing else (and on W, which is the batch's). */
+    int32_t* rep = (int32_t*)sc_alloc(15, sizeof(int32_t) * (size_t)N, 0);
+    if (!rep) { PyErr_NoMemory(); goto fail; }
+    Py_ssize_t n_dup = 0;
+    if (dedup) {
+      size_t cap = 16;
+      while (cap < 2 * (size_t)N) cap <<= 1;
+      int32_t* slots = (int32_t*)sc_alloc(16, sizeof(int32_t) * cap, 0);
+      if (!slots) { PyErr_NoMemory(); goto fail; }
+      memset(slots, 0xff, sizeof(int32_t) * cap);
+      for (Py_ssize_t w = 0; w < N; ++w) {
+        const int32_t* c = cps + cp_off[w];
+        const int32_t lw = lang[sb[w]];
+        uint64_t h = 1469598103934665603ULL ^ (uint64_t)(uint32_t)lw;
+        for (int32_t q2 = 0; q2 < wlen[w]; ++q2) h = (h ^ (uint64_t)(uint32_t)c[q2]) * 1099511628211ULL;
+        size_t sl = (size_t)(h ^ (h >> 29)) & (cap - 1);
+        for (;;) {
+          const int32_t v = slots[sl];
+          if (v < 0) { slots[sl] = (int32_t)w; rep[w] = (int32_t)w; break; }
+          if (wlen[v] == wlen[w] && lang[sb[v]] == lw && memcmp(cps + cp_off[v], c, sizeof(int32_t) * (size_t)wlen[w]) == 0) {
+            rep[w] = v;
+            ++n_dup;
+            break;
+          }
+          sl = (sl + 1) & (cap - 1);
+        }
+      }
+    } else {
+      for (Py_ssize_t w = 0; w < N; ++w) rep[w] = (int32_t)w;
+    }
+    const Py_ssize_t NU = N - n_dup; /* words the character CNN sees */
+
     /* ---- word-length groups of the ragged character CNN (Parser._char_layout) */
     const int MAXG = CUBE_MAX_CONV_GROUPS;
     int cnt[CUBE_MAX_CONV_GROUPS] = {0}, gmax_key[CUBE_MAX_CONV_GROUPS] = {0}, start_key[CUBE_MAX_CONV_GROUPS + 1];
     for (Py_ssize_t w = 0; w < N; ++w) {
+      if (rep[w] != w) continue;
       int key = wlen[w] < 1 ? 1 : wlen[w];
       if (key > MAXG - 1) key = MAXG - 1;
       cnt[key]++;
@@ -549,6 +586,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       int fill[CUBE_MAX_CONV_GROUPS];
       for (int k = 0; k < MAXG; ++k) fill[k] = start_key[k];
       for (Py_ssize_t w = 0; w < N; ++w) { /* stable counting sort */
+        if (rep[w] != w) continue;
         int key = wlen[w] < 1 ? 1 : wlen[w];
         if (key > MAXG - 1) key = MAXG - 1;
         order[fill[key]++] = (int32_t)w;
@@ -586,16 +624,18 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
 
     /* ---- the packed int32 upload (order and 4-element alignment of Parser._prepare) */
     const Py_ssize_t n_char = rows_total[0];
-    Py_ssize_t sizes[10] = {n_char, n_case > 0 ? 0 : n_char, N, N, N, B * T, B * T, B, B, (Py_ssize_t)n * N};
-    Py_ssize_t offs[11];
+    const int n_parts = dedup ? 12 : 10;
+    Py_ssize_t sizes[12] = {n_char, n_case > 0 ? 0 : n_char, NU, NU, NU, B * T, B * T, B, B, (Py_ssize_t)n * NU, n_dup, n_dup};
+    Py_ssize_t offs[13];
     offs[0] = 0;
-    for (int p = 0; p < 10; ++p) offs[p + 1] = offs[p] + (sizes[p] + 3) / 4 * 4;
-    if ((Py_ssize_t)(ibuf.len / 4) < offs[10]) { /* the caller's index buffer is too small: tell it the size, it calls again */
-      result = PyLong_FromSsize_t(offs[10]);
+    for (int p = 0; p < n_parts; ++p) offs[p + 1] = offs[p] + (sizes[p] + 3) / 4 * 4;
+    const Py_ssize_t n_ints = offs[n_parts];
+    if ((Py_ssize_t)(ibuf.len / 4) < n_ints) { /* the caller's index buffer is too small: tell it the size, it calls again */
+      result = PyLong_FromSsize_t(n_ints);
       goto done;
     }
     int32_t* P = (int32_t*)ibuf.buf;
-    memset(P, 0, (size_t)offs[10] * 4);
+    memset(P, 0, (size_t)n_ints * 4);
     {
       int32_t* pc = P + offs[0];
       int32_t* pk = P + offs[1];
@@ -618,11 +658,20 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     {
       int32_t *p_lang = P + offs[2], *p_len = P + offs[3], *p_rowmap = P + offs[4], *p_widx = P + offs[5];
       int32_t *p_lrows = P + offs[6], *p_root = P + offs[7], *p_lens = P + offs[8], *p_wrows = P + offs[9];
-      for (Py_ssize_t a = 0; a < N; ++a) {
+      for (Py_ssize_t a = 0; a < NU; ++a) {
         const int w = order[a];
         p_lang[a] = lang[sb[w]];
         p_len[a] = wlen[w];
         p_rowmap[a] = (int32_t)(sb[w] * T + si[w] + root);
+      }
+      if (dedup) {
+        int32_t *p_dst = P + offs[10], *p_src = P + offs[11];
+        Py_ssize_t d = 0;
+        for (Py_ssize_t w = 0; w < N; ++w)
+          if (rep[w] != w) {
+            p_dst[d] = (int32_t)(sb[w] * T + si[w] + root);
+            p_src[d++] = (int32_t)(sb[rep[w]] * T + si[rep[w]] + root);
+          }
       }
       for (Py_ssize_t w = 0; w < N; ++w) p_widx[sb[w] * T + si[w] + root] = wid[w];
       for (Py_ssize_t b = 0; b < B; ++b) {
@@ -634,7 +683,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         for (int g = 0; g < G; ++g) {
           const int s0 = start_key[gkey[g]];
           for (int a = s0; a < start_key[gkey[g] + 1]; ++a)
-            p_wrows[(Py_ssize_t)l * N + a] = (int32_t)(row0[l + 1][g] + (long)(a - s0) * seq[l + 1][g]);
+            p_wrows[(Py_ssize_t)l * NU + a] = (int32_t)(row0[l + 1][g] + (long)(a - s0) * seq[l + 1][g]);
         }
     }
 
@@ -646,11 +695,11 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     g_t[3] += now_s() - t_start; t_start = now_s();
     ++g_calls;
     PyObject* rows_t = PyTuple_New(n + 1);
-    PyObject* sizes_t = PyTuple_New(10);
+    PyObject* sizes_t = PyTuple_New(n_parts);
     if (!rows_t || !sizes_t) { Py_XDECREF(rows_t); Py_XDECREF(sizes_t); goto fail; }
     for (int k = 0; k <= n; ++k) PyTuple_SET_ITEM(rows_t, k, PyLong_FromLong(rows_total[k]));
-    for (int p = 0; p < 10; ++p) PyTuple_SET_ITEM(sizes_t, p, PyLong_FromSsize_t(sizes[p]));
-    result = Py_BuildValue("(nNnnN)", offs[10], sizes_t, N, W, rows_t);
+    for (int p = 0; p < n_parts; ++p) PyTuple_SET_ITEM(sizes_t, p, PyLong_FromSsize_t(sizes[p]));
+    result = Py_BuildValue("(nNnnN)", n_ints, sizes_t, NU, W, rows_t);
   }
   goto done;
 fail:

@@ -178,7 +178,7 @@ class _HipNet:
 
     # ---- batch preparation -----------------------------------------------------------------
     _PART_NAMES = ("char_idx", "case_idx", "lang_word", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
-                   "lens", "word_rows")
+                   "lens", "word_rows", "dup_dst", "dup_src")  # (the last two: C featuriser with `dedup_words` only)
 
     def _prepare_host(self, X):
         """reference-format batch dict (MorphoCollate.collate_fn) -> the host half of a prepared batch:
@@ -249,7 +249,8 @@ class _HipNet:
             try:
                 r = hm.featurize(batch, enc.word2int, collate._wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
                                  0 if l0 is None else l0["n_case"], L, tuple(b.numpy() for b in st["emb"]), dims,
-                                 ctypes.addressof(groups), self._host_threads, st["ints"].numpy())
+                                 ctypes.addressof(groups), self._host_threads, st["ints"].numpy(),
+                                 1 if self.dedup_words else 0)
             except TypeError:
                 self._staging_release(st)
                 return None
@@ -269,6 +270,10 @@ class _HipNet:
                     staging=st)
 
     _host_threads = 4
+    # Words of a batch with the same spelling and language go through the character CNN once; the other occurrences
+    # copy the first one's char-level vector (bit-identical: a row's result does not depend on the other rows).  Only
+    # the C featuriser builds the lists (`_prepare_host`, the collate_fn route, keeps one row per word).
+    dedup_words = True
     _N_STAGING = 6
 
     def _staging_acquire(self, emb_sizes, n_ints=0):
@@ -342,7 +347,8 @@ class _HipNet:
             ev.record()
             self._staging_release(h["staging"], ev)
         bt.update(B=h["B"], L=h["L"], T=h["T"], N=h["N"], W=h["W"], embs=embs, embs_whole=whole, conv_groups=h["conv_groups"],
-                  char_rows=h["char_rows"], _keep=h.get("_groups_array"))
+                  char_rows=h["char_rows"], _keep=h.get("_groups_array"),
+                  n_dup=int(h["sizes"][10]) if len(h["sizes"]) > 10 else 0)
         if h.get("y_upos") is not None:
             bt["y_upos"] = h["y_upos"].to(dev).to(torch.int32).contiguous()
         return bt
@@ -486,7 +492,7 @@ class _HipNet:
         pool, pool_w = self._char_level(bt)
         # ---- word level input XW0 = [word | char | lang | ext] (+ root row = _r_emb for the parser)
         xw0 = buf.get("xw0", BT, lay.xw0_w)
-        if N != BL:
+        if N + bt.get("n_dup", 0) != BL:
             # pad positions keep a zero char-level vector (unpack, utils.py:17-32); every other element
             # of XW0 is rewritten below for every row.  Without pads nothing needs clearing.
             self._zero(xw0, BT * lay.xw0_w)
@@ -494,6 +500,12 @@ class _HipNet:
         po = pk["char_pre_out"]
         hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
                  col0=lay.xw0_char, n_valid=ch, rowmap=bt["rowmap_word"], stream=st)
+        n_dup = bt.get("n_dup", 0)
+        if n_dup:  # repeated words: the char-level vector of the first occurrence, row to row inside XW0
+            src_hi, src_lo = hip._planes(xw0, lay.xw0_char)
+            hip.check(lib.cube_gather_rows(xw0.hi.data_ptr(), lo(xw0.lo), lay.xw0_w, lay.xw0_char, ch, src_hi,
+                                           src_lo if xw0.lo is not None else None, lay.xw0_w, bt["dup_src"].data_ptr(),
+                                           bt["dup_dst"].data_ptr(), n_dup, st), "cube_gather_rows")
         gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138, tagger.py:111-119)
         cat = pk.get("ext_h1cat") if bt.get("embs_whole") is not None else None

@@ -22,8 +22,10 @@ p, cfg, enc, sd, batches, docs = bench.build_model_and_batches(1, 1, 0, dev, "")
 col = MorphoCollate(enc)
 doc = synth.make_document(enc, [32] * 1024, seed=77, ext_word_emb=(300,))
 big = copy.deepcopy(doc)
-while len(big.sentences) < ns:
-    big.sentences.extend(copy.deepcopy(doc).sentences)
+k = 0
+while len(big.sentences) < ns:  # distinct sentences: copies would let Parser.dedup_words skip most of the character CNN
+    big.sentences.extend(synth.make_document(enc, [32] * 1024, seed=1078 + k, ext_word_emb=(300,)).sentences)
+    k += 1
 p.process(big, col, batch_size=bs, num_workers=0)  # warm-up: allocations, staging ring
 torch.cuda.synchronize()
 pr = cProfile.Profile()

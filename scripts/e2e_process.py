@@ -26,11 +26,12 @@ def main():
     out = {"rows": []}
     n = 16384
     doc = synth.make_document(enc, [32] * 1024, seed=77, ext_word_emb=(300,))
-    # 16k sentences: 16 copies of the words of 1024 (separate objects, separate embedding vectors)
-    import copy
-    big = copy.deepcopy(doc)
+    # 16k DISTINCT sentences (copies of one block would let Parser.dedup_words skip most of the character CNN)
+    big = synth.make_document(enc, [32] * 1024, seed=78, ext_word_emb=(300,))
+    k = 0
     while len(big.sentences) < n:
-        big.sentences.extend(copy.deepcopy(doc).sentences)
+        big.sentences.extend(synth.make_document(enc, [32] * 1024, seed=1078 + k, ext_word_emb=(300,)).sentences)
+        k += 1
     for bs, merge in ((256, True), (32, True), (4, True), (4, False)):  # merged device batches: <= 16384 padded tokens
         m = n if merge else 1024
         sub = big if merge else doc
@@ -42,6 +43,38 @@ def main():
         row = dict(batch_size=bs, merge=merge, sentences=m, seconds=dt, sentences_per_s=m / dt)
         print(json.dumps(row), flush=True)
         out["rows"].append(row)
+    # the same document with word frequencies as text has them (Zipf over a 20000-word pool): what Parser.dedup_words
+    # (one character-CNN row per distinct (spelling, language) pair of a batch) is for
+    import numpy as np
+    zdoc = synth.make_document(enc, [32] * 1024, seed=9078, ext_word_emb=(300,))
+    k = 0
+    while len(zdoc.sentences) < n:
+        zdoc.sentences.extend(synth.make_document(enc, [32] * 1024, seed=10078 + k, ext_word_emb=(300,)).sentences)
+        k += 1
+    pool = list(dict.fromkeys(w.word for s in zdoc.sentences for w in s.words))[:20000]
+    pz = 1.0 / np.arange(1, len(pool) + 1)
+    rng = np.random.default_rng(5)
+    draw = rng.choice(len(pool), size=sum(len(s.words) for s in zdoc.sentences), p=pz / pz.sum())
+    i = 0
+    for s_ in zdoc.sentences:
+        s_.lang_id = zdoc.sentences[0].lang_id
+        for w in s_.words:
+            w.word = pool[draw[i]]
+            i += 1
+    for flag in (False, True):
+        p.dedup_words = flag
+        p.process(zdoc, col, batch_size=256)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p.process(zdoc, col, batch_size=256)
+        dt = time.perf_counter() - t0
+        h = p._featurize(zdoc.sentences[:256], col)
+        row = dict(zipf_text=True, dedup_words=flag, sentences=len(zdoc.sentences), sentences_per_s=len(zdoc.sentences) / dt,
+                   char_cnn_words_of_8192_tokens=int(h["N"]))
+        p._staging_release(h["staging"])
+        print(json.dumps(row), flush=True)
+        out["rows"].append(row)
+    p.dedup_words = True
     # host stages of one 256-sentence batch, one by one (single thread, no overlap)
     batch = big.sentences[:256]
     reps = 20

@@ -21,8 +21,10 @@ p, cfg, enc, sd, batches, docs = bench.build_model_and_batches(1, 1, 0, dev, "")
 col = MorphoCollate(enc)
 doc = synth.make_document(enc, [32] * 1024, seed=77, ext_word_emb=(300,))
 big = copy.deepcopy(doc)
-while len(big.sentences) < 16384:
-    big.sentences.extend(copy.deepcopy(doc).sentences)
+k = 0
+while len(big.sentences) < 16384:  # distinct sentences: copies would let Parser.dedup_words skip most of the character CNN
+    big.sentences.extend(synth.make_document(enc, [32] * 1024, seed=1078 + k, ext_word_emb=(300,)).sentences)
+    k += 1
 acc = defaultdict(float)
 cnt = defaultdict(int)
 

@@ -751,6 +751,39 @@ def test_process_edge_documents(dev):
         assert diff == 0, (diff, len(got))  # measured: identical text (a near-tie flip here would need its margin shown)
 
 
+def test_repeated_words_share_one_character_cnn_row(dev):
+    """`Parser.dedup_words` (the C featuriser hands every (spelling, language) pair of a batch to the character CNN
+    once; the other occurrences copy its char-level vector): the five result columns AND the scores are bit-identical
+    to one row per word, on a document where two thirds of the tokens are drawn from a small pool."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.FULL
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    col = MorphoCollate(enc)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 40, size=48)
+    doc = synth.make_document(enc, lens, seed=41, ext_word_emb=case["ext"])
+    pool = [w.word for s in doc.sentences[:6] for w in s.words]
+    for s in doc.sentences:
+        for w in s.words:
+            if rng.random() < 0.67:
+                w.word = pool[int(rng.integers(len(pool)))]
+    outs = {}
+    for flag in (False, True):
+        p.dedup_words = flag
+        try:
+            h = p._host_batch(list(doc.sentences), col)
+            bt = p._upload(h)
+            assert (bt["n_dup"] > 0) == flag
+            r = p.decode_batch_prepared(bt)
+            outs[flag] = [r[k].clone().cpu().numpy() for k in ("packed", "arc_logits", "label_logits", "upos_logits")]
+        finally:
+            p.dedup_words = True
+    assert bt["n_dup"] > 0.2 * int(lens.sum())  # (the sentences' languages differ, and a repeat needs the same one)
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a, b)
+
+
 def test_process_bucketed_writes_back_in_place(dev):
     """process_bucketed with one bucket = process on the length-sorted document with one batch:
     same batch composition, so the same strings must land on the same Sentence objects."""

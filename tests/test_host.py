@@ -291,6 +291,7 @@ def test_pack_gated_conv_int8_planes():
 
 def _host_dicts(p, col, sents):
     """(C featuriser, collate_fn + _prepare_host) for one batch."""
+    p.dedup_words = False  # one row per word, as collate_fn has them (the dedup lists: test_c_featurizer_dedup_lists)
     fast = p._featurize(list(sents), col)
     assert fast is not None, "the C featuriser refused a batch in the fast format"
     X = col.collate_fn(list(sents), targets=False)
@@ -377,10 +378,61 @@ def test_c_featurizer_full_config_and_generic_objects():
             v.word, v.emb = w.word, w.emb
             t.words.append(v)
         plain.append(t)
+    p.dedup_words = False
     fast2 = p._featurize(plain, col)
     slow2 = p._prepare_host(col.collate_fn(doc.sentences[:5], targets=False))
     _assert_same_host_batch(fast2, slow2)
     p._staging_release(fast2["staging"])
+
+
+def test_c_featurizer_dedup_lists():
+    """`dedup_words`: the per-word arrays hold each (spelling, language) pair once, in the order the one-row-per-word
+    arrays have their first occurrences; every other occurrence is listed with the XW0 row of the first one."""
+    from cube_amd.networks.parser import Parser
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    doc = cases.document(case, enc, "g6")
+    sents = list(doc.sentences[:12])
+    sents[1].words[0].word = sents[0].words[0].word            # the same word in two sentences
+    sents[2].words[-1].word = sents[2].words[0].word           # twice in one sentence
+    sents[3].words[0].word = sents[0].words[0].word.upper() + "Q"
+    sents[4].words[0].word = sents[3].words[0].word
+    p.dedup_words = False
+    full = p._featurize(sents, col)
+    fsz, fpk = list(full["sizes"]), full["packed"].copy()
+    p._staging_release(full["staging"])
+    p.dedup_words = True
+    dd = p._featurize(sents, col)
+    sz, pk = list(dd["sizes"]), dd["packed"]
+    assert len(sz) == 12 and len(fsz) == 10 and sz[10] == sz[11] > 0
+
+    def parts(sizes, packed):
+        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
+        return {n: packed[o:o + s] for n, o, s in zip(p._PART_NAMES, offs[:-1], sizes)}
+    a, b = parts(fsz, fpk), parts(sz, pk)
+    T = dd["T"]
+    words = {}   # XW0 row -> (spelling, language)
+    for bi, s_ in enumerate(sents):
+        for j, w in enumerate(s_.words):
+            words[bi * T + j + p._root] = (w.word, s_.lang_id)
+    n_tok, n_u, n_dup = fsz[2], sz[2], sz[10]
+    assert dd["N"] == n_u and n_u + n_dup == n_tok == len(words)
+    assert len({words[r] for r in b["rowmap_word"]}) == n_u == len(set(words.values()))
+    for d, s_ in zip(b["dup_dst"], b["dup_src"]):
+        assert words[d] == words[s_] and s_ < d and s_ in set(b["rowmap_word"]) and d not in set(b["rowmap_word"])
+    assert sorted(list(b["rowmap_word"]) + list(b["dup_dst"])) == sorted(a["rowmap_word"])
+    # per token arrays are untouched; the kept words keep their relative order and their lengths / languages
+    for k in ("word_idx", "lang_rows", "root_rows", "lens"):
+        np.testing.assert_array_equal(a[k], b[k])
+    keep = np.isin(a["rowmap_word"], b["rowmap_word"])
+    np.testing.assert_array_equal(a["rowmap_word"][keep], b["rowmap_word"])
+    np.testing.assert_array_equal(a["word_len"][keep], b["word_len"])
+    np.testing.assert_array_equal(a["lang_word"][keep], b["lang_word"])
+    assert list(dd["char_rows"]) < list(full["char_rows"])
+    p._staging_release(dd["staging"])
 
 
 def test_c_write_back_equals_python_loop():

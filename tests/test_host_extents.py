@@ -40,6 +40,30 @@ def test_decode_batch_extents(monkeypatch, case, keys, precision):
         assert tuple(r["upos"].shape) == (B, L) and tuple(r["status"].shape) == (B,)
 
 
+def test_repeated_words_extents(monkeypatch):
+    """The batch as the C featuriser hands it over with `dedup_words`: fewer character-CNN words than tokens, and one
+    row-to-row copy inside XW0 for the repeated ones."""
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p, lib = dry_parser(cfg, enc, sd, case["ext"], "bf16x3", monkeypatch)
+    doc = cases.document(case, enc, "g6")
+    sents = list(doc.sentences[:9])
+    for s in sents[1:]:
+        s.words[0].word = sents[0].words[0].word
+        s.lang_id = sents[0].lang_id
+    h = p._host_batch(sents, MorphoCollate(enc))
+    staging, h["staging"] = h["staging"], None  # (no GPU here: no event to hand the pinned buffers back with)
+    bt = p._upload(h)
+    p._staging_release(staging)
+    assert bt["n_dup"] >= 8 and bt["N"] + bt["n_dup"] == sum(len(s.words) for s in sents)
+    lib.extra = [bt]
+    n0 = len(lib.calls)
+    r = p.decode_batch_prepared(bt)
+    assert ("gather", bt["n_dup"], p._lay.char_half) in lib.calls[n0:]
+    assert tuple(r["packed"].shape) == (5, bt["B"], bt["L"])
+
+
 def test_forward_and_get_labels_extents(monkeypatch):
     case = cases.TINY
     cfg, enc, sd = cases.parser_model(case)
