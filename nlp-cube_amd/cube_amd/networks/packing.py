@@ -49,6 +49,26 @@ def gate_column_order(half):
     return order
 
 
+# Weight-quantisation guards of the fixed-point kernels.  A layer runs in int8x2 / 12-bit fixed point only if the
+# relative error its quantised weights put on a dot product with white inputs -- |w_q - w|_2 / |w|_2 of the worst
+# output row -- stays below these bounds; otherwise the packer leaves the fixed-point operands out and the layer
+# (for the gated stacks: the stack) runs in bf16x3.  Per-row scales make the error (max|w| / rms(w)) / (levels *
+# sqrt(12)): 7e-5 for Gaussian rows at 16256 levels, 2.5e-4 for PyTorch's uniform LSTM init at 2032; a checkpoint with
+# outlier weights 4x further out than that is refused instead of trusted.
+I8_CONV_WEIGHT_ERR = 2.5e-4
+LSTM8_WEIGHT_ERR = 1.0e-3
+
+
+def quant_row_error(w, wq):
+    """max over the non-zero rows of |wq - w|_2 / |w|_2 (w, wq: [rows, ...])."""
+    w, wq = w.double().flatten(1), wq.double().flatten(1)
+    den = w.norm(dim=1)
+    ok = den > 0
+    if not bool(ok.any()):
+        return 0.0
+    return float(((wq - w).norm(dim=1)[ok] / den[ok]).max())
+
+
 def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False):
     """-> dict(W bf16 [N, taps*Kc], bias f32 [N], Kc, N, half).
     in_perm: for each column of the HIP activation buffer, the reference input channel (or -1).
@@ -97,6 +117,9 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False)
         def chunks(t):
             return t.view(N, taps, Kc // 64, 64).permute(0, 2, 1, 3).reshape(N, taps * Kc).to(torch.int8).contiguous()
         q8 = dict(W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * 128.0 / (I8_ONE * I8_ONE)).float().contiguous())
+        q_err = quant_row_error(W, q.double() * wmax[:, None, None] / I8_ONE)
+        if q_err > I8_CONV_WEIGHT_ERR:  # outlier weights: this layer's stack stays in bf16x3
+            q8 = dict(int8_refused=q_err)
     # K order of cube_gemm_bf16: 32-channel chunk outer, tap inner
     W = W.view(N, taps, Kc // 32, 32).permute(0, 2, 1, 3).reshape(N, taps * Kc)
     out = dict(W=_bf16(W), bias=bias.contiguous(), Kc=Kc, N=N, half=half, taps=taps)
@@ -292,7 +315,8 @@ def pack_lstm_i8(whh_dirs, H):
     whh_dirs: two f32 [G, >= H] matrices in packed gate-row order (`lstm_gate_rows`; padding rows zero).
     Row n: q = round(w / max|w[n]| * 2032) = 16*hi + lo, hi in [-127, 127] (int8), lo in [-8, 7] stored as the
     nibble lo + 8.  K is padded to a multiple of 32: n64 = KP // 64 fragments of K = 64, then one of K = 32.
-    -> dict(hi uint8 [2, U, 4, WHI_TILE], lo4 uint8 [2, U, 4, WLO_TILE], scale f32 [2, G]) in MFMA-fragment order:
+    -> None when the 12-bit rows miss LSTM8_WEIGHT_ERR, else
+       dict(hi uint8 [2, U, 4, WHI_TILE], lo4 uint8 [2, U, 4, WLO_TILE], scale f32 [2, G]) in MFMA-fragment order:
        hi fragment ks: [lane][16 bytes], byte j of lane (l15, lq) = hi[row u*64 + g*16 + l15][ks*64 + lq*16 + j];
        tail: [lane][8], k = n64*64 + lq*8 + j;  lo4 fragment: [lane][8 bytes] = two words, word m byte b =
        nib[k0 + 4*(2m) + b] | nib[k0 + 4*(2m+1) + b] << 4 with k0 = ks*64 + lq*16; tail: [lane][4], one word."""
@@ -307,6 +331,8 @@ def pack_lstm_i8(whh_dirs, H):
         wp[:, :H] = w[:, :H].double()
         wmax = wp.abs().amax(dim=1).clamp(min=1e-30)
         q = torch.round(wp / wmax[:, None] * LSTM8_WONE).to(torch.int32)
+        if quant_row_error(wp, q.double() * wmax[:, None] / LSTM8_WONE) > LSTM8_WEIGHT_ERR:
+            return None  # outlier weights: this layer keeps the streamed bf16x3 recurrence
         hi = (q + 8) >> 4
         lo = q - (hi << 4)
         assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -8 and int(lo.max()) <= 7

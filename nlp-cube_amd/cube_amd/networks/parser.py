@@ -673,7 +673,7 @@ class Parser(_HipNet):
             dst = xla if l % 2 == 0 else xlb
             hip.gemm(src, src_ld, BT, ih["K"], ih["W"], ih["N"], ih["bias"], hip.EPI_F32, out0=gx, ldo0=G2, n_valid=G2,
                      stream=st)
-            if self.lstm_int8 and self._split:
+            if self.lstm_int8 and self._split and ly.get("whh8") is not None:
                 # hidden-state weights resident in VGPRs + LDS, recurrent product in two-slice int8 fixed point
                 w8 = ly["whh8"]
                 hip.check(lib.cube_bilstm_recurrent_i8(gx.data_ptr(), w8["hi"].data_ptr(), w8["lo4"].data_ptr(),

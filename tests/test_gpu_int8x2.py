@@ -329,3 +329,43 @@ def test_parser_lstm_int8_and_bf16x3_both_match_reference(dev, golden_dir):
         p.lstm_int8 = True
     for key in ("full_8x32", "full_2x128"):
         assert _rel(res[(True, key)], res[(False, key)]) < 2e-4
+
+
+def test_outlier_weights_fall_back_to_bf16x3(dev):
+    """A checkpoint whose weights have outliers far beyond the bulk (here: one weight 60 sigma out in a character
+    layer, a word-level layer and a recurrent matrix) is refused by the packer's fixed-point guards
+    (packing.I8_CONV_WEIGHT_ERR / LSTM8_WEIGHT_ERR): the three stages then run the bf16x3 kernels -- bit-identical to
+    switching the fixed-point paths off by hand -- and stay within the tolerance of the fp32 oracle."""
+    from oracle import parser_oracle
+    from tests.test_gpu_parity import _rel
+    from cube_amd.networks.parser import Parser
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.FULL
+    cfg, enc, sd = cases.parser_model(case)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["_word_net._convolutions_char.2.0.conv.weight"][5, 40, 1] = 3.0
+    sd["_convs.3.0.conv.weight"][100, 7, 4] = -3.0
+    sd["_rnn.weight_hh_l1"][17, 3] = 4.0
+
+    def build(**flags):
+        q = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+        q.load_state_dict(sd)
+        for k, v in flags.items():
+            setattr(q, k, v)
+        return q.to(dev)
+
+    guarded, manual = build(), build(char_int8=False, word_int8=False)
+    pk = guarded._pk_cpu
+    assert "W8" not in pk["char_convs"][2] and "W8" not in pk["word_convs"][3] and pk["lstm"][1]["whh8"] is None
+    assert pk["lstm"][0]["whh8"] is not None and "W8" in pk["char_convs"][1]  # the other layers were admitted
+    doc = cases.document(case, enc, "full_8x32")
+    X = MorphoCollate(enc).collate_fn(doc.sentences, targets=False)
+    a = guarded.decode_batch(X)
+    arc_a, packed_a = a["arc_logits"].cpu().numpy().copy(), a["packed"].cpu().numpy().copy()
+    b = manual.decode_batch(X)
+    # (layers 0 and 2 of the BiLSTM keep the fixed-point recurrence in both models)
+    assert np.array_equal(arc_a, b["arc_logits"].cpu().numpy()) and np.array_equal(packed_a, b["packed"].cpu().numpy())
+    ora = parser_oracle.OracleParser(cfg, enc, sd, list(case["ext"]), quant="fp32")
+    with torch.no_grad():
+        e = ora.decode_batch(X)
+    assert _rel(arc_a, e["arc_logits"]) < 1e-3

@@ -289,6 +289,40 @@ def test_pack_gated_conv_int8_planes():
     assert "W8" not in packing.pack_gated_conv(sd, "c", np.arange(32), int8=True)  # Kc = 32
 
 
+def test_fixed_point_weight_guards():
+    """The packer admits a layer to the fixed-point kernels only if its quantised weights stay within a relative
+    dot-product error (packing.I8_CONV_WEIGHT_ERR / LSTM8_WEIGHT_ERR): every layer of the random-init full-size model
+    passes with room; rows with outliers 60x beyond the bulk are refused (the layer then runs in bf16x3)."""
+    cfg, enc, sd = cases.parser_model(cases.FULL)
+    from cube_amd.networks.parser import Parser
+    p = Parser(cfg, enc, ext_word_emb=[300])
+    p.load_state_dict(sd)
+    pk = p._pk_cpu
+    assert all("W8" in cv for cv in pk["char_convs"][1:]) and all("W8" in cv for cv in pk["word_convs"][1:])
+    assert all(ly["whh8"] is not None for ly in pk["lstm"])
+    g = torch.Generator().manual_seed(9)
+    half, cin = 64, 128
+    w = torch.randn((2 * half, cin, 5), generator=g) * 0.05
+    sdc = {"c.0.conv.weight": w, "c.0.conv.bias": torch.zeros(2 * half),
+           "c.1.weight": torch.ones(2 * half), "c.1.bias": torch.zeros(2 * half),
+           "c.1.running_mean": torch.zeros(2 * half), "c.1.running_var": torch.ones(2 * half)}
+    ok = packing.pack_gated_conv(sdc, "c", np.arange(cin), int8=True)
+    assert "W8" in ok
+    w8 = (ok["W8"].hi.to(torch.int32) * 128 + ok["W8"].lo.to(torch.int32)).double() * (ok["w_scale"].double() * hip.I8_ONE / 128.0)[:, None]
+    wf = ok["W"].float().double().view(ok["N"], cin // 32, 5, 32).permute(0, 2, 1, 3).reshape(ok["N"], -1)
+    w8 = w8.view(ok["N"], cin // 64, 5, 64).permute(0, 2, 1, 3).reshape(ok["N"], -1)
+    assert 2e-5 < packing.quant_row_error(wf, w8) < 1.2e-4   # Gaussian rows: ~4 sigma / (16256 * sqrt(12))
+    w[7, 3, 2] = 3.0                                         # one weight 60 sigma out
+    bad = packing.pack_gated_conv(sdc, "c", np.arange(cin), int8=True)
+    assert "W8" not in bad and bad["int8_refused"] > packing.I8_CONV_WEIGHT_ERR
+    H = 200
+    G = pk["lstm"][0]["G"]
+    hh = [(torch.rand((G, H), generator=g) * 2 - 1) / np.sqrt(H) for _ in range(2)]
+    assert packing.pack_lstm_i8(hh, H) is not None
+    hh[1][5, 17] = 4.0
+    assert packing.pack_lstm_i8(hh, H) is None
+
+
 def _host_dicts(p, col, sents):
     """(C featuriser, collate_fn + _prepare_host) for one batch."""
     p.dedup_words = False  # one row per word, as collate_fn has them (the dedup lists: test_c_featurizer_dedup_lists)
