@@ -181,8 +181,16 @@ def end_to_end(p, enc, docs, n_target=8192):
         p.process(doc, col, batch_size=bs)
         dt = time.perf_counter() - t0
         out["batch_size_%d" % bs] = len(doc.sentences) / dt
+    # the same with word frequencies as text has them: repeated words share one character-CNN row (Parser.dedup_words)
+    synth.zipf_words(doc)
+    p.process(doc, col, batch_size=256)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    p.process(doc, col, batch_size=256)
+    out["batch_size_256_zipf_words"] = len(doc.sentences) / (time.perf_counter() - t0)
     out.update(unit="sentences/s", sentences=len(doc.sentences),
-               what="Parser.process(Document) end to end: featurisation + upload + device + write-back, one host process")
+               what="Parser.process(Document) end to end: featurisation + upload + device + write-back, one host process; "
+                    "zipf_words: the same sentences with Zipf-distributed words (repeated words share a character-CNN row)")
     return out
 
 

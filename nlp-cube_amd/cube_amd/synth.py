@@ -341,3 +341,21 @@ def make_document(enc, sent_lens, seed=0, ext_word_emb=(300,), lang_ids=None, un
         lang = int(rng.integers(enc.num_langs)) if lang_ids is None else int(lang_ids[si])
         doc.sentences.append(Sentence(sequence=rows, lang_id=lang))
     return doc
+
+
+def zipf_words(doc, pool_size=20000, seed=5, one_language=True):
+    """Re-draw every word of `doc` from a pool of its own first `pool_size` distinct words with Zipf frequencies
+    (p_k ~ 1/k), as text has them: most tokens of a batch then repeat, which the all-new words of `make_document` never
+    do.  The embeddings stay per token.  In place; -> doc."""
+    pool = list(dict.fromkeys(w.word for s in doc.sentences for w in s.words))[:pool_size]
+    p = 1.0 / np.arange(1, len(pool) + 1)
+    rng = np.random.default_rng(seed)
+    draw = rng.choice(len(pool), size=sum(len(s.words) for s in doc.sentences), p=p / p.sum())
+    i = 0
+    for s in doc.sentences:
+        if one_language:
+            s.lang_id = doc.sentences[0].lang_id
+        for w in s.words:
+            w.word = pool[draw[i]]
+            i += 1
+    return doc

@@ -45,22 +45,12 @@ def main():
         out["rows"].append(row)
     # the same document with word frequencies as text has them (Zipf over a 20000-word pool): what Parser.dedup_words
     # (one character-CNN row per distinct (spelling, language) pair of a batch) is for
-    import numpy as np
     zdoc = synth.make_document(enc, [32] * 1024, seed=9078, ext_word_emb=(300,))
     k = 0
     while len(zdoc.sentences) < n:
         zdoc.sentences.extend(synth.make_document(enc, [32] * 1024, seed=10078 + k, ext_word_emb=(300,)).sentences)
         k += 1
-    pool = list(dict.fromkeys(w.word for s in zdoc.sentences for w in s.words))[:20000]
-    pz = 1.0 / np.arange(1, len(pool) + 1)
-    rng = np.random.default_rng(5)
-    draw = rng.choice(len(pool), size=sum(len(s.words) for s in zdoc.sentences), p=pz / pz.sum())
-    i = 0
-    for s_ in zdoc.sentences:
-        s_.lang_id = zdoc.sentences[0].lang_id
-        for w in s_.words:
-            w.word = pool[draw[i]]
-            i += 1
+    synth.zipf_words(zdoc)
     for flag in (False, True):
         p.dedup_words = flag
         p.process(zdoc, col, batch_size=256)
