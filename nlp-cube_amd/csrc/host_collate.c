@@ -212,7 +212,7 @@ static inline double now_s(void) {
 
 /* Grow-only scratch buffers of featurize.  The call holds the GIL from start to end, so it cannot overlap itself;
  * keeping the buffers avoids a dozen malloc / mmap / page-fault / munmap rounds of 64..800 KB per batch. */
-enum { SC_SLOTS = 18 };
+enum { SC_SLOTS = 20 };
 static void* g_sc[SC_SLOTS];
 static size_t g_sc_cap[SC_SLOTS];
 static void* sc_alloc(int slot, size_t bytes, int zero) {
@@ -316,6 +316,8 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
   int have_ibuf = 0;
   WordLayout wl;
   wl.tp = NULL;
+  int32_t* cps = NULL;      /* code points of all words, back to back (cp_off) */
+  uint64_t* whash = NULL;   /* FNV-1a of a word's code points (the language is folded in where it is used) */
   EmbJob jobs[16 * 64];     /* the embedding copies run on worker threads beside the index-array pass */
   pthread_t th[16 * 64];
   int n_started = 0;
@@ -367,7 +369,9 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
   order = (int32_t*)sc_alloc(8, sizeof(int32_t) * (size_t)N, 0);
   cp_off = (int32_t*)sc_alloc(9, sizeof(int32_t) * (size_t)(N + 1), 0);
   esrc = (const float**)sc_alloc(10, sizeof(float*) * (size_t)(B * L * (K ? K : 1)), 1); /* NULL = pad row */
-  if (!wstr || !wemb || !wlen || !wid || !sb || !si || !order || !cp_off || !esrc) { PyErr_NoMemory(); goto fail; }
+  whash = (uint64_t*)sc_alloc(17, sizeof(uint64_t) * (size_t)N, 0);
+  cps = (int32_t*)sc_alloc(14, sizeof(int32_t) * (size_t)(8 * N + 64), 0); /* grown in sweep C when the words are longer */
+  if (!wstr || !wemb || !wlen || !wid || !sb || !si || !order || !cp_off || !esrc || !whash || !cps) { PyErr_NoMemory(); goto fail; }
 
   g_t[0] += now_s() - t_start; t_start = now_s();
   /* ---- pass 1: the objects, in sweeps over all words with the next level's memory prefetched a few words
@@ -430,6 +434,35 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       wlen[w] = (int32_t)len;
       if (len > W) W = len;
       cp_off[w] = (int32_t)total_chars;
+      /* the code points, while the string is in the cache: -> cps, their hash, and the ones the table does not know */
+      if ((size_t)(total_chars + len + 1) * sizeof(int32_t) > g_sc_cap[14]) {
+        const size_t cap = 2 * (size_t)(total_chars + len + 1) * sizeof(int32_t);
+        int32_t* grown = (int32_t*)malloc(cap);
+        if (!grown) { PyErr_NoMemory(); bad = 1; break; }
+        memcpy(grown, cps, sizeof(int32_t) * (size_t)total_chars);
+        free(g_sc[14]);
+        g_sc[14] = grown;
+        g_sc_cap[14] = cap;
+        cps = grown;
+      }
+      {
+        const int kind = PyUnicode_KIND(t);
+        const void* data = PyUnicode_DATA(t);
+        uint64_t h = 1469598103934665603ULL;
+        for (Py_ssize_t c = 0; c < len; ++c) {
+          const Py_UCS4 cp = PyUnicode_READ(kind, data, c);
+          cps[total_chars + c] = (int32_t)cp;
+          h = (h ^ (uint64_t)cp) * 1099511628211ULL;
+          if ((Py_ssize_t)cp >= top || tab_char[cp] < 0) {
+            if (!missing) missing = PyList_New(0);
+            PyObject* v = missing ? PyLong_FromLong((long)cp) : NULL;
+            if (!v || PyList_Append(missing, v) != 0) { Py_XDECREF(v); bad = 1; break; }
+            Py_DECREF(v);
+          }
+        }
+        if (bad) break;
+        whash[w] = h;
+      }
       total_chars += len;
       PyObject* id = PyDict_GetItemWithError(wid_cache, t); /* borrowed */
       if (!id) {
@@ -511,30 +544,15 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       if (pthread_create(&th[n_started], NULL, emb_worker, &jobs[n_started]) != 0) break;
     for (int t = n_started; t < nj; ++t) emb_worker(&jobs[t]); /* (no thread to be had: the caller's thread copies) */
   }
-  /* ---- characters: code point -> (char id, case id); unknown code points go back to the caller */
+  /* ---- characters: code point -> (char id, case id); unknown code points (found in sweep C) go back to the caller */
   {
-    int32_t* cps = (int32_t*)sc_alloc(14, sizeof(int32_t) * (size_t)(total_chars + 1), 0);
-    if (!cps) { PyErr_NoMemory(); goto fail; }
-    Py_ssize_t q = 0;
-    for (Py_ssize_t w = 0; w < N; ++w) {
-      const int kind = PyUnicode_KIND(wstr[w]);
-      const void* data = PyUnicode_DATA(wstr[w]);
-      for (Py_ssize_t c = 0; c < wlen[w]; ++c) {
-        const Py_UCS4 cp = PyUnicode_READ(kind, data, c);
-        cps[q++] = (int32_t)cp;
-        if ((Py_ssize_t)cp >= top || tab_char[cp] < 0) {
-          if (!missing) missing = PyList_New(0);
-          PyObject* v = missing ? PyLong_FromLong((long)cp) : NULL;
-          if (!v || PyList_Append(missing, v) != 0) { Py_XDECREF(v); goto fail; }
-          Py_DECREF(v);
-        }
-      }
-    }
     if (missing) {
       result = missing;
       missing = NULL;
       goto done;
     }
+    double t_sub = now_s();
+    g_t[4] += t_sub - t_start;
 
     /* ---- repeated words: rep[w] = the first word of the batch with the same code points and language (itself if
      * there is none).  The character CNN's output for a word depends on nothing else (and on W, which is the batch's). */
@@ -550,8 +568,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       for (Py_ssize_t w = 0; w < N; ++w) {
         const int32_t* c = cps + cp_off[w];
         const int32_t lw = lang[sb[w]];
-        uint64_t h = 1469598103934665603ULL ^ (uint64_t)(uint32_t)lw;
-        for (int32_t q2 = 0; q2 < wlen[w]; ++q2) h = (h ^ (uint64_t)(uint32_t)c[q2]) * 1099511628211ULL;
+        const uint64_t h = (whash[w] ^ (uint64_t)(uint32_t)lw) * 1099511628211ULL;
         size_t sl = (size_t)(h ^ (h >> 29)) & (cap - 1);
         for (;;) {
           const int32_t v = slots[sl];
@@ -568,6 +585,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       for (Py_ssize_t w = 0; w < N; ++w) rep[w] = (int32_t)w;
     }
     const Py_ssize_t NU = N - n_dup; /* words the character CNN sees */
+    g_t[5] += now_s() - t_sub; t_sub = now_s();
 
     /* ---- word-length groups of the ragged character CNN (Parser._char_layout) */
     const int MAXG = CUBE_MAX_CONV_GROUPS;
@@ -622,6 +640,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       }
     }
 
+    g_t[6] += now_s() - t_sub; t_sub = now_s();
     /* ---- the packed int32 upload (order and 4-element alignment of Parser._prepare) */
     const Py_ssize_t n_char = rows_total[0];
     const int n_parts = dedup ? 12 : 10;
@@ -655,6 +674,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         }
       }
     }
+    g_t[7] += now_s() - t_sub;
     {
       int32_t *p_lang = P + offs[2], *p_len = P + offs[3], *p_rowmap = P + offs[4], *p_widx = P + offs[5];
       int32_t *p_lrows = P + offs[6], *p_root = P + offs[7], *p_lens = P + offs[8], *p_wrows = P + offs[9];
@@ -776,9 +796,10 @@ static PyObject* write_back_flat(PyObject* self, PyObject* args) {
   Py_RETURN_NONE;
 }
 
-/* timing() -> (calls, seconds in: sizes pass, object pass, index arrays, embedding copies) since the last call */
+/* timing() -> (calls, seconds in: sizes pass, object pass, index arrays, wait for the embedding copies, and of the index
+ * arrays: code points, repeated words, length groups, character rows) since the last call */
 static PyObject* timing(PyObject* self, PyObject* args) {
-  PyObject* r = Py_BuildValue("(ldddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3]);
+  PyObject* r = Py_BuildValue("(ldddddddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5], g_t[6], g_t[7]);
   g_calls = 0;
   for (int i = 0; i < 8; ++i) g_t[i] = 0.0;
   return r;

@@ -269,7 +269,7 @@ class _HipNet:
                     conv_groups=[groups[l] for l in range(n)], _groups_array=groups, char_rows=list(rows), y_upos=None,
                     staging=st)
 
-    _host_threads = 4
+    _host_threads = 8
     # Words of a batch with the same spelling and language go through the character CNN once; the other occurrences
     # copy the first one's char-level vector (bit-identical: a row's result does not depend on the other rows).  Only
     # the C featuriser builds the lists (`_prepare_host`, the collate_fn route, keeps one row per word).

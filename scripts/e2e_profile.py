@@ -76,6 +76,8 @@ dt = time.perf_counter() - t0
 print("process: %.1f ms for %d sentences = %.0f sentences/s" % (dt * 1e3, len(big.sentences), len(big.sentences) / dt))
 for k in acc:
     print("  %-12s %4d calls  %7.2f ms total  %6.3f ms each" % (k, cnt[k], acc[k] * 1e3, acc[k] / cnt[k] * 1e3))
-c, t0_, t1_, t2_, t3_ = host.load().timing()
+c, t0_, t1_, t2_, t3_, *sub = host.load().timing()
 print("featurize (C), ms per call: sizes %.3f, objects %.3f, index arrays %.3f, embedding copies %.3f (%d calls)"
       % (t0_ / c * 1e3, t1_ / c * 1e3, t2_ / c * 1e3, t3_ / c * 1e3, c))
+print("  of the index arrays: code points %.3f, repeated words %.3f, length groups %.3f, character rows %.3f"
+      % tuple(x / c * 1e3 for x in sub))

@@ -385,6 +385,28 @@ def test_c_featurizer_equals_collate_plus_prepare(which):
     assert h["B"] == 2
 
 
+def test_c_featurizer_very_long_words():
+    """Words of thousands of characters: the featuriser's code-point buffer (sized for 8 characters per word) grows
+    while the strings are being read, and the caller's index buffer is asked for again at its real size."""
+    from cube_amd.networks.parser import Parser
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    doc = cases.document(case, enc, "g6")
+    sents = doc.sentences[:3]
+    sents[0].words[0].word = "ab" * 3000
+    sents[2].words[-1].word = "Zz" * 2500
+    fast, slow = _host_dicts(p, col, sents)
+    assert fast["W"] == 6000
+    _assert_same_host_batch(fast, slow)
+    p._staging_release(fast["staging"])
+    fast, slow = _host_dicts(p, col, doc.sentences[3:6])
+    _assert_same_host_batch(fast, slow)
+    p._staging_release(fast["staging"])
+
+
 def test_c_featurizer_full_config_and_generic_objects():
     """Default ParserConfig (first character layer as table look-ups: combined char x case ids) and plain
     objects without __slots__ (what the reference's own Word / Sentence classes are)."""
