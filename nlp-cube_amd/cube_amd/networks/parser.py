@@ -245,23 +245,30 @@ class _HipNet:
         groups = (hip.ConvGroups * n)()
         enc = collate._encodings
         tab = collate.cp_table32()
-        for _ in range(4):
-            try:
-                r = hm.featurize(batch, enc.word2int, collate._wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
-                                 0 if l0 is None else l0["n_case"], L, tuple(b.numpy() for b in st["emb"]), dims,
-                                 ctypes.addressof(groups), self._host_threads, st["ints"].numpy(),
-                                 1 if self.dedup_words else 0)
-            except TypeError:
+        try:
+            for _ in range(4):
+                try:
+                    r = hm.featurize(batch, enc.word2int, collate._wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
+                                     0 if l0 is None else l0["n_case"], L, tuple(b.numpy() for b in st["emb"]), dims,
+                                     ctypes.addressof(groups), self._host_threads, st["ints"].numpy(),
+                                     1 if self.dedup_words else 0)
+                except TypeError:
+                    self._staging_release(st)
+                    return None
+                if isinstance(r, tuple):
+                    break
+                if isinstance(r, list):
+                    tab = collate.cp_table32(r)  # code points seen for the first time: extend the table, run again
+                else:  # the index buffer was too small (very long words): r = the int32 elements it must hold
+                    st["ints"] = torch.empty(int(r) + int(r) // 4, dtype=torch.int32, pin_memory=self._device.type == "cuda")
+            else:
+                raise RuntimeError("featurize: the character table does not settle")
+        except BaseException:
+            # ValueError (a word that is not a str, a sentence that changed under us), MemoryError, ...: the set goes back
+            # to the ring, or six such errors would leave no staging set for any later call
+            if st["busy"]:
                 self._staging_release(st)
-                return None
-            if isinstance(r, tuple):
-                break
-            if isinstance(r, list):
-                tab = collate.cp_table32(r)  # code points seen for the first time: extend the table, run again
-            else:  # the index buffer was too small (very long words): r = the int32 elements it must hold
-                st["ints"] = torch.empty(int(r) + int(r) // 4, dtype=torch.int32, pin_memory=self._device.type == "cuda")
-        else:
-            raise RuntimeError("featurize: the character table does not settle")
+            raise
         n_ints, sizes, N, W, rows = r
         packed = st["ints"].numpy()[:n_ints]
         embs = [b.numpy()[:B * L * ep].reshape(B * L, ep) for b, (_, ep) in zip(st["emb"], dims)]
@@ -319,29 +326,38 @@ class _HipNet:
         self._require_gpu()
         dev = self._device
         lib = hip.load()
-        ints = torch.from_numpy(h["packed"]).to(dev, non_blocking=True)
-        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in h["sizes"]])])
-        bt = {n: ints[o:o + s] for n, o, s in zip(self._PART_NAMES, offs[:-1], h["sizes"])}
-        embs = []
-        # LM layers of one width land in ONE buffer [K, B*L, Epad] (constant stride: their MLPs' first layers are one
-        # batched launch, `_trunk`)
-        sizes = {e.size for e in h["embs"]}
-        whole = None
-        if len(h["embs"]) > 1 and len(sizes) == 1:
-            n1 = sizes.pop()
-            whole = hip.Pair(torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev),
-                             torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev) if self._split else None)
-        for k, e in enumerate(h["embs"]):
-            src = torch.from_numpy(e).reshape(-1)
-            x = src.to(dev, non_blocking=True)
-            if whole is not None:
-                pair = hip.Pair(whole.hi[k * n1:(k + 1) * n1], None if whole.lo is None else whole.lo[k * n1:(k + 1) * n1])
-            else:
-                pair = hip.Pair(torch.empty(x.numel(), dtype=torch.bfloat16, device=dev),
-                                torch.empty(x.numel(), dtype=torch.bfloat16, device=dev) if self._split else None)
-            hip.check(lib.cube_split_f32(x.data_ptr(), x.numel(), pair.hi.data_ptr(), hip.ptr(pair.lo), hip.stream_handle()),
-                      "cube_split_f32")
-            embs.append(pair)
+        try:
+            ints = torch.from_numpy(h["packed"]).to(dev, non_blocking=True)
+            offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in h["sizes"]])])
+            bt = {n: ints[o:o + s] for n, o, s in zip(self._PART_NAMES, offs[:-1], h["sizes"])}
+            embs = []
+            # LM layers of one width land in ONE buffer [K, B*L, Epad] (constant stride: their MLPs' first layers are one
+            # batched launch, `_trunk`)
+            sizes = {e.size for e in h["embs"]}
+            whole = None
+            if len(h["embs"]) > 1 and len(sizes) == 1:
+                n1 = sizes.pop()
+                whole = hip.Pair(torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev),
+                                 torch.empty(len(h["embs"]) * n1, dtype=torch.bfloat16, device=dev) if self._split else None)
+            for k, e in enumerate(h["embs"]):
+                src = torch.from_numpy(e).reshape(-1)
+                x = src.to(dev, non_blocking=True)
+                if whole is not None:
+                    pair = hip.Pair(whole.hi[k * n1:(k + 1) * n1], None if whole.lo is None else whole.lo[k * n1:(k + 1) * n1])
+                else:
+                    pair = hip.Pair(torch.empty(x.numel(), dtype=torch.bfloat16, device=dev),
+                                    torch.empty(x.numel(), dtype=torch.bfloat16, device=dev) if self._split else None)
+                hip.check(lib.cube_split_f32(x.data_ptr(), x.numel(), pair.hi.data_ptr(), hip.ptr(pair.lo), hip.stream_handle()),
+                          "cube_split_f32")
+                embs.append(pair)
+        except BaseException:
+            if h.get("staging") is not None:  # a failed upload must not keep the pinned set out of the ring
+                try:
+                    torch.cuda.synchronize(dev)  # (copies already enqueued may still read it)
+                except Exception:
+                    pass
+                self._staging_release(h["staging"])
+            raise
         if h["staging"] is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -885,6 +901,12 @@ class Parser(_HipNet):
             for st in self._streams:
                 st.synchronize()
             self._slot_busy = [False] * self.N_SLOTS
+        # staging sets that an exception left marked busy (between featurisation and upload): nothing reads them any more
+        for st in self.__dict__.get("_staging", ()):
+            if st["busy"]:
+                if self._device.type == "cuda":
+                    torch.cuda.synchronize(self._device)
+                self._staging_release(st)
 
     def _write_back(self, batch, start, res, status):
         """parser.py:432-446: ids -> strings, into the Document."""

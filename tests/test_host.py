@@ -385,6 +385,34 @@ def test_c_featurizer_equals_collate_plus_prepare(which):
     assert h["B"] == 2
 
 
+def test_featurizer_errors_give_their_staging_set_back():
+    """A word that is not a str makes `featurize` raise ValueError: more such errors than the ring has sets
+    (`_N_STAGING`) must leave the parser usable — the pinned set goes back on every exception, and `_drain`
+    frees what an exception between featurisation and upload left marked busy."""
+    from cube_amd.networks.parser import Parser
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    doc = cases.document(case, enc, "g6")
+    good = list(doc.sentences[:4])
+    bad = list(cases.document(case, enc, "g6").sentences[4:8])
+    bad[1].words[0].word = 12345
+    for _ in range(p._N_STAGING + 3):
+        with pytest.raises((ValueError, TypeError, AttributeError)):
+            p._host_batch(bad, col)
+    assert not any(st["busy"] for st in p._staging)
+    fast, slow = _host_dicts(p, col, good)
+    _assert_same_host_batch(fast, slow)
+    # sets abandoned between featurisation and upload (an exception in the caller): `_drain` frees them
+    held = [p._featurize(good, col) for _ in range(p._N_STAGING - 1)]
+    assert all(h is not None for h in held) and all(st["busy"] for st in p._staging)
+    p._drain() if hasattr(p, "_drain") else None
+    assert not any(st["busy"] for st in p._staging)
+    assert p._featurize(good, col) is not None
+
+
 def test_c_featurizer_very_long_words():
     """Words of thousands of characters: the featuriser's code-point buffer (sized for 8 characters per word) grows
     while the strings are being read, and the caller's index buffer is asked for again at its real size."""
