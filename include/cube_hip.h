@@ -152,11 +152,11 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
 /* ---- int8x2 fixed point for the gated convolutions whose inputs are gate outputs (|x| < 1) --------
  * Same reference calls as cube_gemm_bf16 / cube_char_conv0_lookup / cube_masked_mean (modules.py:462-483:
  * character-CNN layers >= 1), other operand format.  An activation is two int8 planes,
- *   x = (128*hi + lo) / CUBE_I8_ONE,   hi in [-127, 127], lo in [-64, 63]   (|x| <= 1, step 6.2e-5),
- * a weight row n likewise with its own scale: w[n, k] = (128*hi + lo) * wmax[n] / CUBE_I8_ONE.  The
+ *   x = (256*hi + lo) / CUBE_I8_ONE,   hi in [-127, 127], lo in [-128, 127]   (|x| <= 1, step 3.1e-5: 16 bits),
+ * a weight row n likewise with its own scale: w[n, k] = (256*hi + lo) * wmax[n] / CUBE_I8_ONE.  The
  * products hi*hi and hi*lo + lo*hi are accumulated EXACTLY in int32 on the matrix cores
- * (v_mfma_i32_32x32x32_i8, twice the bf16 rate; lo*lo, 2^-14 relative, is dropped) and
- *   C[r, n] = (128*HH + CROSS) * w_scale[n] + bias,    w_scale[n] = 128 * wmax[n] / CUBE_I8_ONE^2.
+ * (v_mfma_i32_32x32x32_i8, twice the bf16 rate; lo*lo, 2^-16 relative, is dropped) and
+ *   C[r, n] = (256*HH + CROSS) * w_scale[n] + bias,    w_scale[n] = 256 * wmax[n] / CUBE_I8_ONE^2.
  * cube_gemm_i8x2: cube_gemm_args as above with A, A_lo int8 [M, lda], W, W_lo int8 [N, taps*Kc] laid out
  * in 64-channel chunks (W[n, (kc*taps + tap)*64 + c64]), Kc % 64 == 0, lda % 16 == 0, lda / Kc / ldo0 /
  * col0 counted in int8 elements; CUBE_EPI_GATE only, no rowmap; out0, out0_lo int8 planes of the gate
@@ -167,7 +167,8 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
  * aligned (the epilogue reads four floats at a time).
  * cube_char_conv0_lookup_i8 / cube_masked_mean_i8: the bf16 entry points with int8x2 planes as the
  * gate-value output / as the layer inputs (ld_out resp. ld_x in int8 elements, multiples of 16 resp. C % 16 == 0). */
-#define CUBE_I8_ONE 16256 /* 127 * 128 */
+#define CUBE_I8_SHIFT 8
+#define CUBE_I8_ONE 32512 /* 127 << CUBE_I8_SHIFT */
 int cube_gemm_i8x2(const cube_gemm_args* args, const float* w_scale, void* stream);
 int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
                               const cube_conv_groups* groups, int taps, int half, int n_combo,
@@ -203,19 +204,27 @@ int cube_bilstm_recurrent(const float* gx, const void* whh, const void* whh_lo, 
                           void* out, void* out_lo, int ld_out, int col0, void* stream);
 
 /* The same recurrence (torch.lstm, parser.py:71-72,201) with the hidden-state weights RESIDENT in VGPRs and LDS and
- * the product h_{t-1} . W_hh^T in two-slice fixed point on the int8 matrix cores: h = (128*hi + lo) / CUBE_I8_ONE
- * (|h| < 1), a weight row n in 12 bits with its own scale, w[n, k] = (16*hi + lo) * wmax[n] / 2032, hi*hi, hi*lo and
- * lo*hi accumulated exactly in int32 (lo*lo dropped); gates, cell state and the input projections stay fp32.
+ * the product h_{t-1} . W_hh^T in two-slice fixed point on the int8 matrix cores: h = (256*hi + lo) / CUBE_I8_ONE
+ * (|h| < 1, 16 bits), a weight row n with its own scale, an int8 high slice and a low slice of lo_bits = 6 or 4 bits:
+ * w[n, k] = (2^lo_bits * hi + lo) * wmax[n] / (127 * 2^lo_bits); hi*hi, hi*lo and lo*hi accumulated exactly in int32
+ * (lo*lo dropped); gates, cell state and the input projections stay fp32.  cube_bilstm_lo_bits(H) = the widest low
+ * slice that fits the LDS of a CU for this rnn_size (6 up to H = 208, else 4): what the packer should produce.
  * gx, out, out_lo, ld_out, col0 as for cube_bilstm_recurrent (out_lo may be NULL).  KP = H rounded up to 32,
  * n64 = KP / 64, tail = KP % 64 != 0:
  *   whi   int8 [2][U][4][n64*1024 + tail*512]: fragments [lane][16] of hi[row u*64 + g*16 + (lane & 15)]
  *         [ks*64 + (lane >> 4)*16 + j], then the tail [lane][8] at k = n64*64 + (lane >> 4)*8 + j
- *   wlo4  uint8 [2][U][4][n64*512 + tail*256]: the nibbles lo + 8 of the same fragments, two to a byte: 32-bit word m
- *         of a lane, byte b = nib[k0 + 8m + b] | nib[k0 + 8m + 4 + b] << 4
- *   wscale f32 [2][U*64]: 16 * wmax[n] / (CUBE_I8_ONE * 2032) in packed gate-row order.
+ *   wlo   the unsigned values v = lo + 2^(lo_bits-1) of the same fragments, packed:
+ *         lo_bits 4: uint8 [2][U][4][n64*512 + tail*256], two to a byte: 32-bit word m of a lane, byte b =
+ *                    v[k0 + 8m + b] | v[k0 + 8m + 4 + b] << 4
+ *         lo_bits 6: uint8 [2][U][4][n64*768 + tailq*128], a lane's 16 values in three 32-bit words: byte b of word m
+ *                    (m < 3) = v[4m + b] | ((v[12 + b] >> 2m) & 3) << 6; per fragment words 0, 1 of all lanes
+ *                    ([lane][8]), then word 2 of all lanes ([lane][4]); the tail as whole bytes [lane][8] for the
+ *                    first tailq = ceil((16U - 64*n64) / 8) groups of 16 lanes only (the others meet h = 0)
+ *   wscale f32 [2][U*64]: wmax[n] / (CUBE_I8_ONE * 127) in packed gate-row order.
  * Both tensors gx and out must be smaller than 2 GiB (32-bit lane offsets).                                */
-int cube_bilstm_recurrent_i8(const float* gx, const void* whi, const void* wlo4, const float* wscale, int B, int T, int H,
-                             void* out, void* out_lo, int ld_out, int col0, void* stream);
+int cube_bilstm_lo_bits(int H);
+int cube_bilstm_recurrent_i8(const float* gx, const void* whi, const void* wlo, const float* wscale, int B, int T, int H,
+                             int lo_bits, void* out, void* out_lo, int ld_out, int col0, void* stream);
 
 /* Arc scores + row softmax.  u bf16 [B*T, ld_u] (= [h1;1] W), h2 bf16 [B*T, ld_h2] (cols
  * col_h2..col_h2+D), D % 32 == 0.  logits/probs f32 [B, T-1, T]: [b,i,j] = u[b,i+1,:].h2[b,j,:],

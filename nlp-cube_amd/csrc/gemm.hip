@@ -449,8 +449,8 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     const bool ch_ok = ch < p.n_valid;
     const int res_mode = p.res_mode;
     if constexpr (I8) {
-      // int8x2 planes out: pre-activation = (128*hh + cross) * w_scale[col] + bias, the gate value g in
-      // (-1, 1) as q = round(g * CUBE_I8_ONE) = 128*hi + lo with hi in [-127, 127], lo in [-64, 63].
+      // int8x2 planes out: pre-activation = (256*hh + cross) * w_scale[col] + bias, the gate value g in
+      // (-1, 1) as q = round(g * CUBE_I8_ONE) = 256*hi + lo with hi in [-127, 127], lo in [-128, 127].
       // Transposed accumulators (see the MFMA calls): this lane owns activation row i*32 + l31 and, of the
       // wave's 32 channels, c = 8*g + 4*lh + e for register r = 4*g + e -- four consecutive channels per g,
       // i.e. one dword of each int8 plane.  The dwords go through wave-private LDS rows (32 bytes per
@@ -487,15 +487,15 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            const float ca = fmaf((float)acc[i][0][r], 128.f, (float)acc2[i][0][r]) * wa[e] + xa[e];
-            const float cb = fmaf((float)acc[i][1][r], 128.f, (float)acc2[i][1][r]) * wb[e] + xb[e];
+            const float ca = fmaf((float)acc[i][0][r], (float)(1 << CUBE_I8_SHIFT), (float)acc2[i][0][r]) * wa[e] + xa[e];
+            const float cb = fmaf((float)acc[i][1][r], (float)(1 << CUBE_I8_SHIFT), (float)acc2[i][1][r]) * wb[e] + xb[e];
             const float gv = tanhf_(ca) * sigmoidf_(cb);
             gq[e] = gv;
             int q = __float2int_rn(gv * (float)CUBE_I8_ONE);
             q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-            const int h = (q + 64) >> 7;
+            const int h = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
             dh |= (uint32_t)(h & 255) << (8 * e);
-            dl |= (uint32_t)((q - (h << 7)) & 255) << (8 * e);
+            dl |= (uint32_t)((q - (h << CUBE_I8_SHIFT)) & 255) << (8 * e);
           }
           *reinterpret_cast<uint32_t*>(stg + l31 * SROW8 + 8 * g + 4 * lh) = dh;
           *reinterpret_cast<uint32_t*>(stg + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
@@ -616,13 +616,13 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         if (row >= 0 && ch_ok) {
           const float g = tanhf_(acc[i][0][r] + ba[r]) * sigmoidf_(acc[i][1][r] + bb[r]);
           if (out0 && res_mode != 3) {
-            if (p.out0_i8) {  // the next layer reads int8x2 planes (cube_gemm_i8x2): q = round(g * CUBE_I8_ONE) = 128*hi + lo
+            if (p.out0_i8) {  // the next layer reads int8x2 planes (cube_gemm_i8x2): q = round(g * CUBE_I8_ONE) = 256*hi + lo
               int q = __float2int_rn(g * (float)CUBE_I8_ONE);
               q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-              const int h = (q + 64) >> 7;
+              const int h = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
               const size_t o = (size_t)row * p.ldo0 + p.col0 + ch;
               reinterpret_cast<signed char*>(out0)[o] = (signed char)h;
-              reinterpret_cast<signed char*>(out0_lo)[o] = (signed char)(q - (h << 7));
+              reinterpret_cast<signed char*>(out0_lo)[o] = (signed char)(q - (h << CUBE_I8_SHIFT));
             } else {
               store_bf16(out0, out0_lo, (size_t)row * p.ldo0 + p.col0 + ch, g);
             }

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 13; }
+extern "C" int cube_abi_version(void) { return 14; }
 
 namespace {
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void masked_mean_i8_kernel(MeanLayers ly, int 
         for (int j = 0; j < 16; ++j) {
           const int hq = (int)(int8_t)(wh[j >> 2] >> (8 * (j & 3)));
           const int lq = (int)(int8_t)(wl[j >> 2] >> (8 * (j & 3)));
-          sk[j] += (hq << 7) + lq;
+          sk[j] += (hq << CUBE_I8_SHIFT) + lq;
         }
       }
     }
@@ -283,15 +283,15 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   const float4 bb = *reinterpret_cast<const float4*>(bp + half);
   const float gv[4] = {tanhf_(a.x + ba.x) * sigmoidf_(b.x + bb.x), tanhf_(a.y + ba.y) * sigmoidf_(b.y + bb.y),
                        tanhf_(a.z + ba.z) * sigmoidf_(b.z + bb.z), tanhf_(a.w + ba.w) * sigmoidf_(b.w + bb.w)};
-  if constexpr (I8) {  // int8x2 planes (cube_hip.h): q = round(g * CUBE_I8_ONE) = 128*hi + lo
+  if constexpr (I8) {  // int8x2 planes (cube_hip.h): q = round(g * CUBE_I8_ONE) = 256*hi + lo
     uint32_t ph = 0, pl = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int q = __float2int_rn(gv[k] * (float)CUBE_I8_ONE);
       q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-      const int hq = (q + 64) >> 7;
+      const int hq = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
       ph |= (uint32_t)(hq & 0xff) << (8 * k);
-      pl |= (uint32_t)((q - (hq << 7)) & 0xff) << (8 * k);
+      pl |= (uint32_t)((q - (hq << CUBE_I8_SHIFT)) & 0xff) << (8 * k);
     }
     const size_t ob = (size_t)row * ld_out + c4;  // bytes
     *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + ob) = ph;

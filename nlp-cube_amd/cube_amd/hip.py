@@ -10,13 +10,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 13  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 14  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
 
 MAX_CONV_GROUPS = 32
-I8_ONE = 16256  # CUBE_I8_ONE: int8x2 fixed point, x = (128*hi + lo) / I8_ONE
+I8_SHIFT = 8    # CUBE_I8_SHIFT
+I8_ONE = 127 << I8_SHIFT  # CUBE_I8_ONE: int8x2 fixed point, x = (256*hi + lo) / I8_ONE (16 bits)
+LSTM8_HONE = I8_ONE  # hidden states of cube_bilstm_recurrent_i8: the same 16-bit planes
 
 
 class ConvGroups(ctypes.Structure):
@@ -105,7 +107,8 @@ SIGNATURES = {
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cube_bilstm_recurrent": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                       c_int, c_void_p]),
-    "cube_bilstm_recurrent_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+    "cube_bilstm_lo_bits": (c_int, [c_int]),
+    "cube_bilstm_recurrent_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_int, c_int, c_void_p]),
     "cube_biaffine_arc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),

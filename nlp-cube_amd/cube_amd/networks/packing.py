@@ -53,9 +53,9 @@ def gate_column_order(half):
 # relative error its quantised weights put on a dot product with white inputs -- |w_q - w|_2 / |w|_2 of the worst
 # output row -- stays below these bounds; otherwise the packer leaves the fixed-point operands out and the layer
 # (for the gated stacks: the stack) runs in bf16x3.  Per-row scales make the error (max|w| / rms(w)) / (levels *
-# sqrt(12)): 7e-5 for Gaussian rows at 16256 levels, 2.5e-4 for PyTorch's uniform LSTM init at 2032; a checkpoint with
+# sqrt(12)): 3.5e-5 for Gaussian rows at 32512 levels, 2.5e-4 for PyTorch's uniform LSTM init at 2032 levels (4-bit low slices; 6.2e-5 at the 8128 of 6-bit ones); a checkpoint with
 # outlier weights 4x further out than that is refused instead of trusted.
-I8_CONV_WEIGHT_ERR = 2.5e-4
+I8_CONV_WEIGHT_ERR = 1.25e-4
 LSTM8_WEIGHT_ERR = 1.0e-3
 
 
@@ -79,7 +79,7 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False)
     W[:, channels, t] @ table[g]  (m = the taps that fall inside the sequence at a position).
     `bias_tab_q` is the same from bf16-rounded weights and table (single-pass "bf16" contract).
     int8: also `W8` (Pair of int8 planes [N, taps*Kc], 64-channel chunks) and `w_scale` f32 [N] for
-    cube_gemm_i8x2: w[n, :] = (128*hi + lo) * max|w[n, :]| / I8_ONE (include/cube_hip.h)."""
+    cube_gemm_i8x2: w[n, :] = (256*hi + lo) * max|w[n, :]| / I8_ONE (include/cube_hip.h)."""
     w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
     b = sd[prefix + ".0.conv.bias"].float()
     s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
@@ -107,16 +107,16 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False)
     bias[valid_n] = b[src_n]
     q8 = None
     if int8 and Kc % 64 == 0:
-        from cube_amd.hip import I8_ONE, Pair
+        from cube_amd.hip import I8_ONE, I8_SHIFT, Pair
         wmax = W.abs().amax(dim=(1, 2)).double().clamp(min=1e-30)
         q = torch.round(W.double() / wmax[:, None, None] * I8_ONE).to(torch.int32)
-        hi = (q + 64) >> 7  # arithmetic shift = floor: hi in [-127, 127], lo in [-64, 63]
-        lo = q - (hi << 7)
-        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -64 and int(lo.max()) <= 63
+        hi = (q + (1 << (I8_SHIFT - 1))) >> I8_SHIFT  # arithmetic shift = floor: hi in [-127, 127], lo in [-128, 127]
+        lo = q - (hi << I8_SHIFT)
+        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -128 and int(lo.max()) <= 127
 
         def chunks(t):
             return t.view(N, taps, Kc // 64, 64).permute(0, 2, 1, 3).reshape(N, taps * Kc).to(torch.int8).contiguous()
-        q8 = dict(W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * 128.0 / (I8_ONE * I8_ONE)).float().contiguous())
+        q8 = dict(W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * float(1 << I8_SHIFT) / (I8_ONE * I8_ONE)).float().contiguous())
         q_err = quant_row_error(W, q.double() * wmax[:, None, None] / I8_ONE)
         if q_err > I8_CONV_WEIGHT_ERR:  # outlier weights: this layer's stack stays in bf16x3
             q8 = dict(int8_refused=q_err)
@@ -307,56 +307,86 @@ def lstm_gate_rows(H):
     return rows
 
 
-LSTM8_WONE = 2032  # 127 * 16: 12-bit recurrent weights, w = (16*hi + lo) * wmax / LSTM8_WONE (csrc/lstm_i8.hip)
+def lstm8_lo_bits(H):
+    """Bits of the low slice of W_hh in cube_bilstm_recurrent_i8: 6 when the packed slices of a direction fit the LDS of a
+    CU beside the h images (H <= 208), else 4 (= cube_bilstm_lo_bits of include/cube_hip.h, restated for the packer)."""
+    U = (H + 15) // 16
+    KP = 32 * ((U + 1) // 2)
+    n64 = KP // 64
+    tailq = (16 * U - 64 * n64 + 7) // 8 if KP % 64 else 0
+    lds6 = 4 * 16 * (KP + 16) + U * 4 * (n64 * 768 + tailq * 128) + U * 256
+    return 6 if lds6 <= 160 * 1024 else 4
 
 
-def pack_lstm_i8(whh_dirs, H):
+def pack_lstm_i8(whh_dirs, H, lo_bits=None):
     """Recurrent weights of one BiLSTM layer for cube_bilstm_recurrent_i8 (include/cube_hip.h).
     whh_dirs: two f32 [G, >= H] matrices in packed gate-row order (`lstm_gate_rows`; padding rows zero).
-    Row n: q = round(w / max|w[n]| * 2032) = 16*hi + lo, hi in [-127, 127] (int8), lo in [-8, 7] stored as the
-    nibble lo + 8.  K is padded to a multiple of 32: n64 = KP // 64 fragments of K = 64, then one of K = 32.
-    -> None when the 12-bit rows miss LSTM8_WEIGHT_ERR, else
-       dict(hi uint8 [2, U, 4, WHI_TILE], lo4 uint8 [2, U, 4, WLO_TILE], scale f32 [2, G]) in MFMA-fragment order:
+    Row n: q = round(w / max|w[n]| * 127 * 2^lo_bits) = 2^lo_bits * hi + lo, hi in [-127, 127] (int8), lo stored as the
+    unsigned v = lo + 2^(lo_bits - 1).  K is padded to a multiple of 32: n64 = KP // 64 fragments of K = 64, then one of
+    K = 32.  lo_bits: 6 (default when it fits the LDS, `lstm8_lo_bits`) or 4.
+    -> None when the quantised rows miss LSTM8_WEIGHT_ERR, else
+       dict(hi uint8 [2, U, 4, WHI_TILE], lo uint8 [2, U, 4, WLO_TILE], scale f32 [2, G], lo_bits) in MFMA-fragment order:
        hi fragment ks: [lane][16 bytes], byte j of lane (l15, lq) = hi[row u*64 + g*16 + l15][ks*64 + lq*16 + j];
-       tail: [lane][8], k = n64*64 + lq*8 + j;  lo4 fragment: [lane][8 bytes] = two words, word m byte b =
-       nib[k0 + 4*(2m) + b] | nib[k0 + 4*(2m+1) + b] << 4 with k0 = ks*64 + lq*16; tail: [lane][4], one word."""
-    from cube_amd.hip import I8_ONE
+       tail: [lane][8], k = n64*64 + lq*8 + j;
+       lo, 4 bits: fragment [lane][8 bytes] = two words, word m byte b = v[k0 + 4*(2m) + b] | v[k0 + 4*(2m+1) + b] << 4
+       with k0 = ks*64 + lq*16; tail: [lane][4], one word;
+       lo, 6 bits: three words per lane, word m byte b = v[k0 + 4m + b] | ((v[k0 + 12 + b] >> 2m) & 3) << 6, stored as
+       [lane][words 0, 1] then [lane][word 2] per fragment;
+       tail: whole bytes [lane][8] for the first tailq groups of 16 lanes (the columns a hidden unit < 16 U can reach)."""
+    from cube_amd.hip import LSTM8_HONE
+    if lo_bits is None:
+        lo_bits = lstm8_lo_bits(H)
+    assert lo_bits in (4, 6)
+    wstep = 1 << lo_bits
+    wone = 127 * wstep
     G = whh_dirs[0].shape[0]
     U = G // 64
     KP = 32 * ((U + 1) // 2)
     n64, tail = KP // 64, (KP % 64) != 0
+    tailq = (16 * U - 64 * n64 + 7) // 8 if tail else 0
     his, los, scales = [], [], []
     for w in whh_dirs:
         wp = torch.zeros((G, KP), dtype=torch.float64)
         wp[:, :H] = w[:, :H].double()
         wmax = wp.abs().amax(dim=1).clamp(min=1e-30)
-        q = torch.round(wp / wmax[:, None] * LSTM8_WONE).to(torch.int32)
-        if quant_row_error(wp, q.double() * wmax[:, None] / LSTM8_WONE) > LSTM8_WEIGHT_ERR:
+        q = torch.round(wp / wmax[:, None] * wone).to(torch.int32)
+        if quant_row_error(wp, q.double() * wmax[:, None] / wone) > LSTM8_WEIGHT_ERR * 16 / wstep:
             return None  # outlier weights: this layer keeps the streamed bf16x3 recurrence
-        hi = (q + 8) >> 4
-        lo = q - (hi << 4)
-        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -8 and int(lo.max()) <= 7
-        nib = (lo + 8).to(torch.uint8)
+        hi = (q + wstep // 2) >> lo_bits
+        lo = q - (hi << lo_bits)
+        assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -(wstep // 2) and int(lo.max()) < wstep // 2
+        v = (lo + wstep // 2).to(torch.uint8)
         hi8 = hi.to(torch.int8).view(torch.uint8)
         r = hi8.view(U, 4, 16, KP)                                   # [u][g][l15][k]
-        nb = nib.view(U, 4, 16, KP)
+        nb = v.view(U, 4, 16, KP)
         hp, lp = [], []
         for ks in range(n64):
             f = r[:, :, :, ks * 64:(ks + 1) * 64].reshape(U, 4, 16, 4, 16)          # [u][g][l15][lq][j]
             hp.append(f.permute(0, 1, 3, 2, 4).reshape(U, 4, 1024))                  # lane = lq*16 + l15
             n_ = nb[:, :, :, ks * 64:(ks + 1) * 64].reshape(U, 4, 16, 4, 4, 4)       # [u][g][l15][lq][reg m][byte b]
-            pk = (n_[..., 0::2, :] | (n_[..., 1::2, :] << 4))                        # [u][g][l15][lq][2][4]
-            lp.append(pk.permute(0, 1, 3, 2, 4, 5).reshape(U, 4, 512))
+            if lo_bits == 4:
+                pk = (n_[..., 0::2, :] | (n_[..., 1::2, :] << 4))                    # [u][g][l15][lq][2][4]
+                lp.append(pk.permute(0, 1, 3, 2, 4, 5).reshape(U, 4, 512))
+            else:
+                top = n_[..., 3, :]                                                  # the values 12 + b: two bits into each word
+                pk = torch.stack([n_[..., m, :] | (((top >> (2 * m)) & 3) << 6) for m in range(3)], dim=-2)  # [..][lq][3][4]
+                pk = pk.permute(0, 1, 3, 2, 4, 5)                                    # [u][g][lq][l15][3][4]
+                lp.append(torch.cat([pk[..., :2, :].reshape(U, 4, 512), pk[..., 2, :].reshape(U, 4, 256)], dim=2))
         if tail:
             f = r[:, :, :, n64 * 64:n64 * 64 + 32].reshape(U, 4, 16, 4, 8)
             hp.append(f.permute(0, 1, 3, 2, 4).reshape(U, 4, 512))
-            n_ = nb[:, :, :, n64 * 64:n64 * 64 + 32].reshape(U, 4, 16, 4, 2, 4)     # [..][lq][reg m][byte b]
-            pk = (n_[..., 0, :] | (n_[..., 1, :] << 4))                              # [u][g][l15][lq][4]
-            lp.append(pk.permute(0, 1, 3, 2, 4).reshape(U, 4, 256))
+            if lo_bits == 4:
+                n_ = nb[:, :, :, n64 * 64:n64 * 64 + 32].reshape(U, 4, 16, 4, 2, 4)  # [..][lq][reg m][byte b]
+                pk = (n_[..., 0, :] | (n_[..., 1, :] << 4))                          # [u][g][l15][lq][4]
+                lp.append(pk.permute(0, 1, 3, 2, 4).reshape(U, 4, 256))
+            else:
+                n_ = nb[:, :, :, n64 * 64:n64 * 64 + 8 * tailq].reshape(U, 4, 16, tailq, 8)   # [u][g][l15][lq][j]
+                lp.append(n_.permute(0, 1, 3, 2, 4).reshape(U, 4, tailq * 128))
         his.append(torch.cat(hp, dim=2))
         los.append(torch.cat(lp, dim=2))
-        scales.append((16.0 * wmax / (I8_ONE * LSTM8_WONE)).float())
-    return dict(hi=torch.stack(his).contiguous(), lo4=torch.stack(los).contiguous(), scale=torch.stack(scales).contiguous())
+        scales.append((wmax / (LSTM8_HONE * 127.0)).float())
+    return dict(hi=torch.stack(his).contiguous(), lo=torch.stack(los).contiguous(), scale=torch.stack(scales).contiguous(),
+                lo_bits=lo_bits)
 
 
 def pack_parser(sd, cfg, enc_sizes, ext_dims):

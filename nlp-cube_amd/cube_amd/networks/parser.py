@@ -692,9 +692,9 @@ class Parser(_HipNet):
             if self.lstm_int8 and self._split and ly.get("whh8") is not None:
                 # hidden-state weights resident in VGPRs + LDS, recurrent product in two-slice int8 fixed point
                 w8 = ly["whh8"]
-                hip.check(lib.cube_bilstm_recurrent_i8(gx.data_ptr(), w8["hi"].data_ptr(), w8["lo4"].data_ptr(),
-                                                       w8["scale"].data_ptr(), B, T, H, dst.hi.data_ptr(), lo(dst.lo), xl_w, 0,
-                                                       st), "cube_bilstm_recurrent_i8")
+                hip.check(lib.cube_bilstm_recurrent_i8(gx.data_ptr(), w8["hi"].data_ptr(), w8["lo"].data_ptr(),
+                                                       w8["scale"].data_ptr(), B, T, H, w8["lo_bits"], dst.hi.data_ptr(),
+                                                       lo(dst.lo), xl_w, 0, st), "cube_bilstm_recurrent_i8")
             else:
                 hip.check(lib.cube_bilstm_recurrent(gx.data_ptr(), ly["whh"].hi.data_ptr(), lo(ly["whh"].lo), B, T, H,
                                                     dst.hi.data_ptr(), lo(dst.lo), xl_w, 0, st), "cube_bilstm_recurrent")

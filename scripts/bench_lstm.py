@@ -30,17 +30,17 @@ for d in range(2):
     wp = torch.zeros((G, packing.p32(H)), dtype=torch.float32)
     wp[torch.from_numpy(v), :H] = w[torch.from_numpy(rows1[v])]
     whh.append(wp)
-pk = packing.pack_lstm_i8(whh, H)
+pk = packing.pack_lstm_i8(whh, H, int(os.environ["WLO"]) if "WLO" in os.environ else None)
 gx = torch.randn((B * T, 2 * G), device=dev)
 ld = packing.p32(2 * H + 64)
 out = torch.zeros((B * T, ld), dtype=torch.bfloat16, device=dev)
 out_lo = torch.zeros_like(out)
-d_hi, d_lo, d_sc = pk["hi"].to(dev), pk["lo4"].to(dev), pk["scale"].to(dev)
+d_hi, d_lo, d_sc = pk["hi"].to(dev), pk["lo"].to(dev), pk["scale"].to(dev)
 st = torch.cuda.current_stream().cuda_stream
 
 
 def run8():
-    hip.check(fn8(gx.data_ptr(), d_hi.data_ptr(), d_lo.data_ptr(), d_sc.data_ptr(), B, T, H, out.data_ptr(), out_lo.data_ptr(),
+    hip.check(fn8(gx.data_ptr(), d_hi.data_ptr(), d_lo.data_ptr(), d_sc.data_ptr(), B, T, H, pk["lo_bits"], out.data_ptr(), out_lo.data_ptr(),
                   ld, 0, st), "cube_bilstm_recurrent_i8")
 
 

@@ -267,7 +267,7 @@ class TraceLib:
         self._need("argmax out", out, 4 * M, 4)
         return 0
 
-    def cube_bilstm_recurrent_i8(self, gx, whi, wlo4, wscale, B, T, H, out, out_lo, ld_out, col0, stream):
+    def cube_bilstm_recurrent_i8(self, gx, whi, wlo, wscale, B, T, H, lo_bits, out, out_lo, ld_out, col0, stream):
         self.calls.append(("bilstm_i8", B, T, H))
         U = (H + 15) // 16
         KP = 32 * ((U + 1) // 2)
@@ -275,7 +275,9 @@ class TraceLib:
         assert col0 + 2 * H <= ld_out
         self._need("bilstm_i8 gx", gx, 4 * B * T * 2 * U * 64, 4)
         self._need("bilstm_i8 whi", whi, 2 * U * 4 * (n64 * 1024 + tail * 512), 16)
-        self._need("bilstm_i8 wlo4", wlo4, 2 * U * 4 * (n64 * 512 + tail * 256), 16)
+        assert lo_bits in (4, 6)
+        tailq = (16 * U - 64 * n64 + 7) // 8 if tail else 0
+        self._need("bilstm_i8 wlo", wlo, 2 * U * 4 * ((n64 * 512 + tail * 256) if lo_bits == 4 else (n64 * 768 + tailq * 128)), 16)
         self._need("bilstm_i8 wscale", wscale, 4 * 2 * U * 64, 4)
         for nm, p in (("out", out), ("out_lo", out_lo)):
             self._need("bilstm_i8 " + nm, p, 2 * ((B * T - 1) * ld_out + col0 + 2 * H), 2)

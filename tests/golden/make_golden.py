@@ -149,6 +149,36 @@ def forward_fixture(name, case, doc_keys, with_weights):
     print(name, len(save), "arrays")
 
 
+def g11_bench_batches():
+    """The first batch of `bench.py` (rank 0) at configs 1 and 2 -- 256 sentences x 32 tokens and 64 x 128, seed 1000,
+    default ParserConfig, weights seed 1234 -- through the REFERENCE at that batch size: `Parser.forward`, soft-max,
+    `ChuLiuEdmondsDecoder.decode`, `_get_labels`, the arg-maxes of `process` (parser.py:412-431).  8192 tokens each:
+    the size at which north_star's 99.9 % decision agreement can be asserted.  Stored: arc logits and UPOS logits of
+    every token, heads / labels / UPOS ids, the two largest label logits of every token and the label logits of the
+    first 16 sentences."""
+    p, cfg, enc, sd = build_ref_parser(cases.FULL)
+    col = REF["MorphoCollate"](ref_encodings(enc))
+    dec = REF["CLE"]()
+    for tag, B, L in (("config1_256x32", 256, 32), ("config2_64x128", 64, 128)):
+        doc = synth.make_document(enc, [L] * B, seed=1000, ext_word_emb=(300,))
+        batch = col.collate_fn(ref_document(doc).sentences)
+        del batch["y_upos"]
+        with torch.no_grad():
+            att, labels, upos, xpos, attrs, _, _, _ = p.forward(batch)
+            sl = batch["x_sent_len"].numpy()
+            heads = dec.decode(torch.softmax(att, dim=-1).numpy(), sl)
+            lab = p._get_labels(labels, heads)
+        hp = np.stack([np.asarray(h) for h in heads]).astype(np.int16)
+        top2 = torch.topk(lab, 2, dim=-1).values.numpy().astype(np.float32)
+        save = dict(arc_logits=att.numpy().astype(np.float32), upos_logits=upos.numpy().astype(np.float32), heads=hp,
+                    labels=torch.argmax(lab, -1).numpy().astype(np.int16), upos=torch.argmax(upos, -1).numpy().astype(np.int16),
+                    xpos=torch.argmax(xpos, -1).numpy().astype(np.int16), attrs=torch.argmax(attrs, -1).numpy().astype(np.int16),
+                    label_top2=top2, label_logits16=lab[:16].numpy().astype(np.float32),
+                    label_absmax=np.float32(lab.abs().max().item()))
+        np.savez_compressed(os.path.join(HERE, "g11_bench_%s.npz" % tag), **save)
+        print("g11", tag, {k: np.shape(v) for k, v in save.items()}, flush=True)
+
+
 def g4_mst():
     dec = REF["CLE"]()
     save = {}
@@ -288,7 +318,7 @@ def g9_lemmatizer():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which:
         g1_collate()
     if "g2" in which:
@@ -307,3 +337,5 @@ if __name__ == "__main__":
         g9_lemmatizer()
     if "g10" in which:
         g10_tokenizer()
+    if "g11" in which:
+        g11_bench_batches()
