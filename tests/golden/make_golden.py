@@ -209,6 +209,26 @@ def g6_process():
             print("g6", tag, bs)
 
 
+def g6_arcs():
+    """The arc scores behind the G6 texts: `Parser.forward` on every batch that `process` forms (parser.py:408-421) at
+    batch sizes 4 and 32 -- so that a head that differs from a G6 text can be held to north_star's rule (equal
+    wherever the reference's margin exceeds the tolerance) instead of to luck."""
+    save = {}
+    for case, tag in ((cases.TINY, "tiny"), (cases.FULL, "full")):
+        p, cfg, enc, sd = build_ref_parser(case)
+        col = REF["MorphoCollate"](ref_encodings(enc))
+        sents = ref_document(cases.document(case, enc, "g6")).sentences
+        for bs in (4, 32):
+            for start in range(0, len(sents), bs):
+                batch = col.collate_fn(sents[start:start + bs])
+                del batch["y_upos"]
+                with torch.no_grad():
+                    att = p.forward(batch)[0]
+                save["%s/bs%d/%d" % (tag, bs, start)] = att.numpy().astype(np.float32)
+        print("g6a", tag)
+    np.savez_compressed(os.path.join(HERE, "g6_process_arcs.npz"), **save)
+
+
 def g7_tagger():
     save = {}
     for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
@@ -318,7 +338,7 @@ def g9_lemmatizer():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g6a", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which:
         g1_collate()
     if "g2" in which:
@@ -329,6 +349,8 @@ if __name__ == "__main__":
         g4_mst()
     if "g6" in which:
         g6_process()
+    if "g6a" in which:
+        g6_arcs()
     if "g7" in which:
         g7_tagger()
     if "g8" in which:

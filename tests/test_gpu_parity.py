@@ -581,19 +581,56 @@ def test_forward_api_outputs(dev, golden_dir):
 @pytest.mark.parametrize("tag,case", [("tiny", cases.TINY), ("full", cases.FULL)])
 @pytest.mark.parametrize("bs", [4, 32])
 def test_process_document_text_matches_reference(dev, golden_dir, tag, case, bs):
-    """Parser.process end to end against the REFERENCE's CoNLL-U text (golden G6, both batch
-    sizes: results depend on batch composition): identical text."""
+    """Parser.process end to end against the REFERENCE's CoNLL-U text (golden G6, both batch sizes: results depend on
+    batch composition).  The text is identical except where north_star allows a difference: a sentence whose tree
+    differs must be a near-tie of the reference's own objective by the derived bound
+    (`_assert_trees_differ_only_at_near_ties`, with the reference's arc scores of that batch from g6_process_arcs.npz),
+    only HEAD and DEPREL columns of such a sentence may differ, and at most one sentence of the 32 may (measured: three
+    of the four texts identical, one head of 405 in the fourth)."""
     from cube_amd.networks.utils import MorphoCollate
     p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    col = MorphoCollate(enc)
     doc = cases.document(case, enc, "g6")
-    p.process(doc, MorphoCollate(enc), batch_size=bs, num_workers=0)
+    p.process(doc, col, batch_size=bs, num_workers=0)
     with open(os.path.join(golden_dir, "g6_process_%s_bs%d.conllu" % (tag, bs)), encoding="utf-8") as f:
         exp = f.read().split("\n")
     got = str(doc).split("\n")
     assert len(got) == len(exp)
-    diff = sum(x != y for x, y in zip(got, exp))
-    print("process %s bs%d: %d of %d lines differ" % (tag, bs, diff, len(got)))
-    assert diff == 0, diff  # measured: identical in all four cases
+    diff = [i for i, (x, y) in enumerate(zip(got, exp)) if x != y]
+    print("process %s bs%d: %d of %d lines differ" % (tag, bs, len(diff), len(got)))
+    if not diff:
+        return
+    # which sentences (blocks separated by empty lines) hold the differing lines
+    sent_of_line, k = [], 0
+    for line in exp:
+        sent_of_line.append(k)
+        if line == "":
+            k += 1
+    bad_sents = sorted({sent_of_line[i] for i in diff})
+    assert len(bad_sents) <= 1, bad_sents
+    for i in diff:
+        x, y = got[i].split("\t"), exp[i].split("\t")
+        assert len(x) == len(y) == 10 and [c for c in range(10) if x[c] != y[c]] in ([6], [7], [6, 7]), (got[i], exp[i])
+    arcs = np.load(os.path.join(golden_dir, "g6_process_arcs.npz"))
+    ref_doc_heads = [[int(l.split("\t")[6]) for l in blk.split("\n") if l] for blk in "\n".join(exp).split("\n\n") if blk.strip()]
+    for sidx in bad_sents:
+        start = sidx // bs * bs
+        sents = doc.sentences[start:start + bs]
+        r = p.decode_batch(col.collate_fn(sents, targets=False))   # the reference batch this sentence was scored in
+        torch.cuda.synchronize()
+        ref_arc = arcs["%s/bs%d/%d" % (tag, bs, start)]
+        arc = r["arc_logits"].cpu().numpy()
+        assert _rel(arc, ref_arc) < REL_TOL
+        sl = [len(s_.words) for s_ in sents]
+        L = max(sl)
+        heads = np.zeros((len(sents), L), dtype=np.int64)
+        ref_heads = np.zeros((len(sents), L), dtype=np.int64)
+        for b_, s_ in enumerate(sents):
+            heads[b_, :sl[b_]] = [int(w.head) for w in s_.words]
+            ref_heads[b_, :sl[b_]] = ref_doc_heads[start + b_]
+        np.testing.assert_array_equal(heads, r["heads"].cpu().numpy())   # what process wrote = this batch's decode
+        gap = _assert_trees_differ_only_at_near_ties(arc, ref_arc, heads, ref_heads, sl)
+        print("  sentence %d: the reference's objective prefers its own tree by %.3g nats" % (sidx, gap))
 
 
 # ------------------------------------------------------------------------------------------
@@ -681,12 +718,29 @@ def _is_single_rooted_tree(heads):
     return True
 
 
+def test_config1_full_batch_matches_reference(dev, golden_dir):
+    """BASELINE configs[1] at full size: exactly the first batch of `bench.py` (256 sentences x 32 tokens, seed 1000,
+    default ParserConfig, weights seed 1234) in the DEFAULT precision -- the mode bench.py reports as `dtype` -- against
+    the reference's own outputs for that batch (G11): all 8192 tokens, >= 99.9 % of heads / labels / UPOS / XPOS / ATTRS
+    equal, scores within 1e-3, every differing tree a near-tie by the derived bound."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    p, cfg, enc, sd = _model(dev, cases.FULL, "bf16x3")
+    assert p.char_int8 and p.word_int8 and p.lstm_int8   # the fixed-point stages are on: this IS the benchmarked mode
+    g = np.load(os.path.join(golden_dir, "g11_bench_config1_256x32.npz"))
+    doc = synth.make_document(enc, [32] * 256, seed=1000, ext_word_emb=(300,))
+    r = p.decode_batch(MorphoCollate(enc).collate_fn(doc.sentences, targets=False))
+    torch.cuda.synchronize()
+    got = _check_batch_against_reference(r, g, [32] * 256, min_agree=0.999)
+    print("config 1 full batch vs the reference:", got)
+
+
 def test_full_size_batch_properties(dev):
     """The bench workload itself (256 sentences x 32 tokens, default config): (1) every decoded
     sentence is a single-rooted tree; (2) a sentence's scores do not depend on how many other
     sentences share the batch — bitwise, when padded word length and sentence length are the
     same (rows are independent and their K order is fixed); (3) a sub-batch agrees with the fp32
-    oracle to the north-star tolerance."""
+    oracle to the north-star tolerance (the whole batch: `test_config1_full_batch_matches_reference`)."""
     from oracle import parser_oracle
     from cube_amd import synth
     from cube_amd.networks.utils import MorphoCollate
@@ -925,6 +979,76 @@ def test_very_long_words_match_oracle(dev, n_chars):
 # ------------------------------------------------------------------------------------------
 # BASELINE configs[2] and configs[3] at full size / full width against the oracle
 # ------------------------------------------------------------------------------------------
+def _log_softmax64(x):
+    x = x.astype(np.float64)
+    m = x.max(axis=-1, keepdims=True)
+    return x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True))
+
+
+def _assert_trees_differ_only_at_near_ties(arc, ref_arc, heads, ref_heads, sl):
+    """`exact agreement wherever the score margin exceeds tolerance`, for trees: the decoder maximises the sum of
+    log p over the arcs of a single-rooted tree (utils.py:520-563), so when the device's tree T_d differs from the
+    reference's T_o, the reference's own objective may prefer T_o by no more than the score perturbation can explain:
+        S_o(T_o) - S_o(T_d) = [S_o(T_o) - S_d(T_o)] + [S_d(T_o) - S_d(T_d)] + [S_d(T_d) - S_o(T_d)]
+                            <= sum over the words whose head differs of |dlogp(k, T_o[k])| + |dlogp(k, T_d[k])|
+    (the middle term is <= 0: T_d maximises S_d; arcs in both trees cancel), where dlogp is the difference of the
+    two log-soft-maxes over all T columns (parser.py:425) -- itself bounded through the 1e-3 score tolerance that the
+    caller asserts.  No free parameter: the allowance is computed from the scores at hand."""
+    lp_o, lp_d = _log_softmax64(ref_arc), _log_softmax64(arc)
+    worst = 0.0
+    for b in np.where((heads != ref_heads).any(axis=1))[0]:
+        n = int(sl[b])
+        if n == 0:
+            continue
+        k = np.arange(n)
+        ho, hd = ref_heads[b, :n].astype(np.int64), heads[b, :n].astype(np.int64)
+        assert _is_single_rooted_tree(hd), b
+        diff = ho != hd
+        if not diff.any():
+            continue
+        gap = lp_o[b, k, ho].sum() - lp_o[b, k, hd].sum()
+        allow = (np.abs(lp_o[b, k, ho] - lp_d[b, k, ho])[diff] + np.abs(lp_o[b, k, hd] - lp_d[b, k, hd])[diff]).sum()
+        assert gap <= allow + 1e-9, (int(b), float(gap), float(allow), int(diff.sum()))
+        worst = max(worst, gap)
+    return worst
+
+
+def _check_batch_against_reference(r, g, sl, min_agree=0.999):
+    """One decoded device batch against the REFERENCE's own outputs for it (tests/golden/g11_bench_*.npz, made by
+    tests/golden/make_golden.py from adobe/NLP-Cube's Parser.forward / ChuLiuEdmondsDecoder / _get_labels): north_star's
+    bar on all tokens of the batch -- arc / label / UPOS scores within 1e-3 relative, heads, labels and UPOS equal on
+    >= 99.9 % of the tokens and wherever the reference's margin exceeds the tolerance."""
+    B, L = len(sl), int(max(sl))
+    mask = np.arange(L)[None, :] < np.asarray(sl)[:, None]
+    arc, ref_arc = r["arc_logits"].cpu().numpy(), g["arc_logits"]
+    assert _rel(arc, ref_arc) < REL_TOL, _rel(arc, ref_arc)
+    assert _rel_elem(arc, ref_arc) < REL_TOL, _rel_elem(arc, ref_arc)
+    upos_log = r["upos_logits"].cpu().numpy()
+    assert _rel(upos_log, g["upos_logits"]) < REL_TOL
+    tol_abs = REL_TOL * np.abs(g["upos_logits"]).max()
+    nbad, agree = _margin_ok(g["upos_logits"][mask], r["upos"].cpu().numpy()[mask], g["upos"][mask], tol_abs)
+    assert nbad == 0 and agree >= min_agree, ("upos", nbad, agree)
+    assert (r["status"].cpu().numpy() == 0).all()
+    heads, ref_heads = r["heads"].cpu().numpy(), g["heads"].astype(np.int64)
+    agree_h = float((heads[mask] == ref_heads[mask]).mean())
+    assert agree_h >= min_agree, ("heads", agree_h, int((heads != ref_heads)[mask].sum()))
+    _assert_trees_differ_only_at_near_ties(arc, ref_arc, heads, ref_heads, sl)
+    # labels are scored for the decoded head (parser.py:218-233): comparable where the heads agree
+    same = mask & (heads == ref_heads)
+    labels = r["labels"].cpu().numpy()
+    lab_tol = REL_TOL * float(g["label_absmax"])
+    margin = g["label_top2"][..., 0] - g["label_top2"][..., 1]
+    wrong = same & (labels != g["labels"])
+    assert not (wrong & (margin > lab_tol)).any(), ("labels", int((wrong & (margin > lab_tol)).sum()))
+    agree_l = 1.0 - wrong.sum() / max(int(same.sum()), 1)
+    assert agree_l >= min_agree, ("labels", agree_l)
+    lab16 = r["label_logits"].cpu().numpy()[:16]
+    assert _rel(lab16[same[:16]], g["label_logits16"][same[:16]]) < REL_TOL
+    for k in ("xpos", "attrs"):
+        assert float((r[k].cpu().numpy()[mask] == g[k][mask]).mean()) >= min_agree, k
+    return dict(heads=agree_h, heads_differ=int((heads != ref_heads)[mask].sum()), labels=float(agree_l), upos=agree)
+
+
 def _check_batch_against_oracle(p, r, e, sl, min_agree=0.999):
     """One decoded device batch `r` against the fp32 oracle's `e` on the same batch composition: scores within
     1e-3 relative, decisions equal on >= 99.9 % of tokens and wherever the oracle's margin exceeds the tolerance."""
@@ -945,15 +1069,8 @@ def _check_batch_against_oracle(p, r, e, sl, min_agree=0.999):
         ref_heads[b, :len(h)] = h
     assert (r["status"].cpu().numpy() == 0).all()
     assert (heads[mask] == ref_heads[mask]).mean() >= min_agree, (heads[mask] == ref_heads[mask]).mean()
-    # exact wherever the margin exceeds the tolerance: a sentence whose tree differs must be a near-tie of the
-    # decoder's own objective (sum of log p over the arcs, utils.py:551-552) under the ORACLE's probabilities
-    for b in np.where((heads != ref_heads)[:, :L].any(axis=1) & mask.any(axis=1))[0]:
-        n = int(sl[b])
-        pr = e["arc_probs"][b].astype(np.float64)
-        so = np.log(pr[np.arange(n), ref_heads[b, :n]]).sum()
-        sd = np.log(pr[np.arange(n), heads[b, :n]]).sum()
-        assert _is_single_rooted_tree(heads[b, :n]), b
-        assert abs(so - sd) <= 2 * REL_TOL * n, (b, so, sd)
+    # exact wherever the margin exceeds the tolerance
+    _assert_trees_differ_only_at_near_ties(arc, e["arc_logits"], heads, ref_heads, sl)
     same = mask & (heads == ref_heads)
     lab = r["label_logits"].cpu().numpy()
     assert _rel(lab[same], e["label_logits"][same]) < REL_TOL
@@ -985,14 +1102,14 @@ def test_sentence_of_300_words_matches_oracle(dev):
     assert [int(w.head) for w in doc.sentences[0].words] == heads[0, :300].tolist()
 
 
-def test_config2_full_size(dev):
+def test_config2_full_size(dev, golden_dir):
     """BASELINE configs[2] at full size: exactly the first batch of `bench.py --config 2` (64 sentences x 128
     tokens, default ParserConfig, weights seed 1234).  (1) every tree single-rooted; (2) the MST heads of all 64
     sentences BIT-EQUAL to the NumPy restatement of the reference decoder run on the kernel's own arc
     probabilities — at this size the ~1000 rooted re-runs keep their score matrices in the workspace
     (MST_ROOT_GLOBAL_N), a mode the fixtures do not reach; (3) an 8-sentence sub-batch of the same padded
-    geometry is bitwise the full batch's rows and agrees with the fp32 oracle (parser.py:404-448,
-    utils.py:520-577)."""
+    geometry is bitwise the full batch's rows; (4) the whole batch against the REFERENCE's outputs (G11) at
+    north_star's 99.9 % (parser.py:404-448, utils.py:520-577)."""
     from oracle import parser_oracle, cle_oracle
     from cube_amd import synth
     from cube_amd.networks.utils import MorphoCollate
@@ -1025,18 +1142,14 @@ def test_config2_full_size(dev):
     np.testing.assert_array_equal(rs["arc_logits"].cpu().numpy(), arc[keep])
     np.testing.assert_array_equal(rs["heads"].cpu().numpy(), heads[keep])
     np.testing.assert_array_equal(rs["label_logits"].cpu().numpy(), lab[keep])
-    # the fp32 oracle on the WHOLE batch (8192 tokens: the 99.9 % bar needs that many)
+    # the WHOLE batch (8192 tokens: the 99.9 % bar needs that many) against the reference's own outputs for it (G11), in the
+    # default precision = the mode `bench.py --config 2` reports
+    assert p.char_int8 and p.word_int8 and p.lstm_int8
     r = p.decode_batch(X)
-    ora = parser_oracle.OracleParser(cfg, enc, sd, [300], quant="fp32")
-    torch.set_num_threads(16)
-    with torch.no_grad():
-        e = ora.decode_batch(parser_oracle.collate(doc.sentences, enc))
-    # Token agreement of the heads: with random-init weights the arc margins are of the size of the fp32 round-off (all
-    # kernels in bf16x3: 3 of 8192 tokens differ from the oracle, arc scores 3.0e-5; each int8x2 stage adds a few:
-    # character CNN 4, + BiLSTM 7, + word-level layers 11 = 99.87 %, arc scores 4.2e-5; scripts/word_i8_study.py), and
-    # one flipped arc moves a subtree.  Every differing tree must be a near-tie of the decoder's objective (checked
-    # inside), scores stay 25x inside the 1e-3 bar; the 99.9 % figure holds on config 1 (8192 tokens in 256 sentences).
-    _check_batch_against_oracle(p, r, e, [L] * B, min_agree=0.998)
+    torch.cuda.synchronize()
+    g = np.load(os.path.join(golden_dir, "g11_bench_config2_64x128.npz"))
+    got = _check_batch_against_reference(r, g, [L] * B, min_agree=0.999)
+    print("config 2 full batch vs the reference:", got)
 
 
 def test_config3_ragged_multiflavour_full_width(dev):
