@@ -593,19 +593,23 @@ class _HipNet:
             src, src_ld = dst, lay.xw_w
         return out
 
-    def _tag_heads(self, bt, slot, x, x_w, upos_key, emb_col):
+    def _tag_heads(self, bt, slot, x, x_w, upos_key, emb_col, row_off=0, cap_rows=None):
         """UPOS logits -> arg-max (or gold tags) -> UPOS embedding into columns [emb_col, emb_col+64)
-        of `x` -> ATTRS | XPOS logits; arg-max of all three (parser.py:180-192, tagger.py:153-161)."""
+        of `x` -> ATTRS | XPOS logits; arg-max of all three (parser.py:180-192, tagger.py:153-161).
+        row_off / cap_rows: the slot's result buffers hold `cap_rows` positions and this batch writes its rows from
+        `row_off` on (several batches whose later stages run together, `Parser.submit`)."""
         lib, pk, buf, st = hip.load(), self._pk, self._buf, hip.stream_handle()
         B, T = bt["B"], bt["T"]
         BT, root = B * T, self._root
+        cap = BT if cap_rows is None else cap_rows
         sfx = "_%d" % slot
         n_u, n_x, n_a = self._sizes["upos"], self._sizes["xpos"], self._sizes["attrs"]
-        upos_log = buf.get("upos_log" + sfx, BT, n_u, torch.float32)[:BT * n_u].view(BT, n_u)
+        upos_log = buf.get("upos_log" + sfx, cap, n_u, torch.float32)[row_off * n_u:(row_off + BT) * n_u].view(BT, n_u)
         q = pk[upos_key]
         hip.gemm(x, x_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=upos_log, ldo0=n_u, n_valid=n_u,
                  stream=st)
-        tag_idx = buf.get("tag_idx" + sfx, 3, BT, torch.int32)[:3 * BT].view(3, BT)  # upos, attrs, xpos
+        tag_all = buf.get("tag_idx" + sfx, 3, cap, torch.int32)[:3 * cap].view(3, cap)  # upos, attrs, xpos
+        tag_idx = tag_all[:, row_off:row_off + BT]
         hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, tag_idx[0].data_ptr(), st), "cube_argmax_rows")
         emb_idx = tag_idx[0]
         if "y_upos" in bt:  # gold tags given (training-time behaviour of forward, parser.py:185-188)
@@ -616,12 +620,12 @@ class _HipNet:
         self._gather(x, x_w, emb_col, 64, pk["upos_emb"], emb_idx, None, BT)
         q = pk["attrs_xpos"]
         n_ax = q["n_valid"]
-        ax_log = buf.get("ax_log" + sfx, BT, n_ax, torch.float32)[:BT * n_ax].view(BT, n_ax)
+        ax_log = buf.get("ax_log" + sfx, cap, n_ax, torch.float32)[row_off * n_ax:(row_off + BT) * n_ax].view(BT, n_ax)
         hip.gemm(x, x_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
                  stream=st)
         hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, 0, n_a, BT, tag_idx[1].data_ptr(), st), "cube_argmax_rows")
         hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, n_a, n_x, BT, tag_idx[2].data_ptr(), st), "cube_argmax_rows")
-        return dict(tag_idx=tag_idx,
+        return dict(tag_idx=tag_idx, tag_all=tag_all,
                     upos_logits=upos_log.view(B, T, n_u)[:, root:, :], ax_logits=ax_log.view(B, T, n_ax)[:, root:, :],
                     upos=tag_idx[0].view(B, T)[:, root:], attrs=tag_idx[1].view(B, T)[:, root:],
                     xpos=tag_idx[2].view(B, T)[:, root:])
@@ -636,22 +640,26 @@ class Parser(_HipNet):
         self._decoder = ChuLiuEdmondsDecoder()
         self._streams = None
 
-    def _front(self, bt, slot=0, want_aux=False):
+    def _front(self, bt, slot=0, want_aux=False, row_off=0, cap_rows=None):
         """GEMM-heavy first phase: char CNN, ext MLPs, word CNN, morphology heads.  Leaves the LSTM
-        input in xl0_{slot} and the tag logits in slot buffers."""
+        input in xl0_{slot} and the tag logits in slot buffers -- from row `row_off` of buffers that hold
+        `cap_rows` positions when several batches share the slot's later stages (`submit`)."""
         pk, lay, buf, st = self._pk, self._lay, self._buf, hip.stream_handle()
         BT = bt["B"] * bt["T"]
+        cap = BT if cap_rows is None else cap_rows
         wh, lg, P = lay.word_half, lay.lang, lay.P
         # XL0 = [x_parse | lang | ext] (LSTM input), XM = [hidden | lang] (morphology input)
         xl0_w = p32(wh + lg + P)
-        xl0 = buf.get("xl0_%d" % slot, BT, xl0_w)
+        xl0_all = buf.get("xl0_%d" % slot, cap, xl0_w)
         # XL0: x_parse, lang and ext columns are rewritten for every word row each batch; only the ext
         # columns of the root rows must read zero (parser.py:195-197), and they do as long as the
-        # (B, T) layout of this slot's buffer has not changed since it was last cleared
+        # (rows, T) layout of this slot's buffer has not changed since it was last cleared (root rows sit at multiples of T)
         lay_key = "xl0_layout_%d" % slot
-        if self._layouts.get(lay_key) != (bt["B"], bt["T"]):
-            self._zero(xl0, BT * xl0_w)
-            self._layouts[lay_key] = (bt["B"], bt["T"])
+        if self._layouts.get(lay_key) != (cap, bt["T"]):
+            self._zero(xl0_all, cap * xl0_w)
+            self._layouts[lay_key] = (cap, bt["T"])
+        o = row_off * xl0_w
+        xl0 = xl0_all if row_off == 0 else hip.Pair(xl0_all.hi[o:], None if xl0_all.lo is None else xl0_all.lo[o:])
         xm_w = p32(wh + lg)
         xm = buf.get("xm", BT, xm_w)
         out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,
@@ -663,8 +671,8 @@ class Parser(_HipNet):
         q = pk["pre_morpho"]
         hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
                  n_valid=q["n_valid"], stream=st)
-        out.update(self._tag_heads(bt, slot, pm, pm_w, "upos", wh + lg))
-        out.update(xl0=xl0, xl0_w=xl0_w)
+        out.update(self._tag_heads(bt, slot, pm, pm_w, "upos", wh + lg, row_off, cap_rows))
+        out.update(xl0=xl0_all, xl0_w=xl0_w)
         return out
 
     def _back(self, bt, fr, slot=0):
@@ -820,7 +828,28 @@ class Parser(_HipNet):
         return self._decode(bt, self._encode(bt))
 
     # ---- pipelined execution: GEMM-heavy phase of batch i+1 overlaps the latency-bound phase of i ----
-    N_SLOTS = 3
+    # Batches are taken in GROUPS of up to `PAIR`: each batch runs its own first stage (its own geometry: longest word,
+    # its own ragged character layouts), writing the LSTM input and the tag decisions into the group's buffers behind
+    # those of the batches before it; the latency-bound later stages -- input projections, the recurrent kernels,
+    # pre_parsing, the arc scorer, MST decoding, the label scorer, the D->H copy -- then run ONCE for the group as one
+    # batch of all its sentences.  Every row of those stages depends on its own sentence only (the bitwise
+    # batch-independence the parity suite checks), so results do not change; what changes is that the 3 x T serial
+    # recurrent steps, the decoder's task waves and a dozen launch-bound small GEMMs are paid once per group.
+    PAIR = int(os.environ.get("CUBE_PAIR", "3"))  # batches per group (same sentence length; the later ones no larger than the first)
+    N_SLOTS = 2 * PAIR + 1   # batches that may be in flight (submitted, not collected)
+    N_GROUPS = N_SLOTS       # groups in flight: as many as batches, for when no two consecutive batches share a length
+
+    def _init_pipeline(self):
+        # Three streams, one per stage, and no more: how HIP maps streams to its (by default 4) hardware queues
+        # depends on what else created streams in the process (RCCL under torch.distributed does), and two stages
+        # that land on one queue run one after the other.  A decode stream per slot was measured: 117k..159k
+        # sentences/s depending on GPU_MAX_HW_QUEUES and on whether RCCL was loaded; one decode stream:
+        # 154k..159k in all four combinations, and config 2 no slower (16.7k).
+        self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
+        self._groups = [dict(free=None, host=None, pending=0, members=[], open=False, done=None) for _ in range(self.N_GROUPS)]
+        self._open = None
+        self._n_groups = 0
+        self._buf.streams = self._streams
 
     @hip.on_device
     def submit(self, bt):
@@ -828,79 +857,127 @@ class Parser(_HipNet):
         heads (GEMMs that fill all CUs), (2) BiLSTM, pre_parsing and the arc scorer (a few persistent
         workgroups, serial steps), (3) MST decode, label scorer and the D->H copy of the results.  The
         stages of one batch run in order (events); the latency-bound stages 2 and 3 of earlier batches
-        run under stage 1 of later ones.  Returns a ticket for `collect`.  At most `N_SLOTS` batches
-        may be in flight (submitted, not collected)."""
+        run under stage 1 of later ones, and they run once per GROUP of `PAIR` consecutive batches of the same
+        sentence length (above): a batch's stages 2 and 3 are enqueued when its group is full, when a batch that does
+        not fit the group arrives, or when `collect` asks for it.  Returns a ticket for `collect`.  At most `N_SLOTS`
+        batches may be in flight (submitted, not collected)."""
         self._require_gpu()
         if self._streams is None:
-            # Three streams, one per stage, and no more: how HIP maps streams to its (by default 4) hardware queues
-            # depends on what else created streams in the process (RCCL under torch.distributed does), and two stages
-            # that land on one queue run one after the other.  A decode stream per slot was measured: 117k..159k
-            # sentences/s depending on GPU_MAX_HW_QUEUES and on whether RCCL was loaded; one decode stream:
-            # 154k..159k in all four combinations, and config 2 no slower (16.7k).
-            self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
-            self._slot_free = [None] * self.N_SLOTS
-            self._host_res = [None] * self.N_SLOTS
-            self._slot_busy = [False] * self.N_SLOTS
-            self._n_submitted = 0
-            self._buf.streams = self._streams
-        slot = self._n_submitted % self.N_SLOTS
-        if self._slot_busy[slot]:
-            # the slot's pinned result buffer is still waiting to be read by `collect`: a fourth batch in
-            # flight would let its D->H copy overwrite results the host has not taken yet
+            self._init_pipeline()
+        B, L, T = bt["B"], bt["L"], bt["T"]
+        if sum(x["pending"] for x in self._groups) >= self.N_SLOTS:
             raise hip.CubeHipError("Parser.submit: %d batches are in flight, collect() the oldest first" % self.N_SLOTS)
-        self._slot_busy[slot] = True
-        self._n_submitted += 1
-        s1, s2, s3 = self._streams
+        g = self._open
+        if g is not None:
+            grp = self._groups[g]
+            if grp["T"] != T or grp["rows"] + B * T > grp["cap"] or len(grp["members"]) >= self.PAIR:
+                self._close_group(g)
+                g = None
+        s1 = self._streams[0]
         cur = torch.cuda.current_stream()
-        B, L = bt["B"], bt["L"]
+        if g is None:
+            # a group whose batches have all been collected (its pinned result buffer has been read): the one used
+            # longest ago first; with fewer than N_SLOTS = N_GROUPS batches in flight there always is one
+            free = [k for k in range(self.N_GROUPS) if not self._groups[k]["pending"]]
+            g = min(free, key=lambda k: self._groups[k].get("serial", -1))
+            grp = self._groups[g]
+            self._n_groups += 1
+            grp["serial"] = self._n_groups
+            grp.update(members=[], open=True, T=T, L=L, rows=0, cap=self.PAIR * B * T, done=None, B=0)
+            self._open = g
+            if grp["free"] is not None:
+                s1.wait_event(grp["free"])  # the later stages of the group that used these buffers last
         with torch.cuda.stream(s1):
             s1.wait_stream(cur)  # inputs uploaded on the caller's stream
-            if self._slot_free[slot] is not None:
-                s1.wait_event(self._slot_free[slot])
-            fr = self._front(bt, slot)
+            fr = self._front(bt, g, row_off=grp["rows"], cap_rows=grp["cap"])
             ev_front = torch.cuda.Event()
             ev_front.record(s1)
+        # the ticket keeps the batch's device inputs alive until `collect`: they were allocated on the
+        # caller's stream, and freeing them earlier would let the next upload reuse their memory
+        # while the kernels of this batch (on the stage streams) still read it
+        ticket = dict(group=g, serial=self._n_groups, b_off=grp["B"], B=B, L=L, bt=bt)
+        grp["members"].append(ticket)
+        grp.update(rows=grp["rows"] + B * T, B=grp["B"] + B, fr=fr, ev_front=ev_front, pending=grp["pending"] + 1)
+        if len(grp["members"]) >= self.PAIR:
+            self._close_group(g)
+        return ticket
+
+    def _close_group(self, g):
+        """Stages 2 and 3 for all the batches of group `g` as one batch."""
+        grp = self._groups[g]
+        if not grp["open"]:
+            return
+        grp["open"] = False
+        if self._open == g:
+            self._open = None
+        s1, s2, s3 = self._streams
+        B, L, T = grp["B"], grp["L"], grp["T"]
+        members = grp["members"]
         with torch.cuda.stream(s2):
-            s2.wait_event(ev_front)
-            r = self._back(bt, fr, slot)
+            s2.wait_event(grp["ev_front"])  # recorded after the group's last first stage; the stream is in order
+            if len(members) == 1:
+                vbt = members[0]["bt"]
+            else:  # the index arrays of the group's rows, one after the other
+                lang = self._buf.get("grp_lang_%d" % g, grp["cap"], 1, torch.int32)
+                lens = self._buf.get("grp_lens_%d" % g, grp["cap"], 1, torch.int32)
+                for m in members:
+                    lang[m["b_off"] * T:(m["b_off"] + m["B"]) * T].copy_(m["bt"]["lang_rows"], non_blocking=True)
+                    lens[m["b_off"]:m["b_off"] + m["B"]].copy_(m["bt"]["lens"], non_blocking=True)
+                vbt = dict(B=B, L=L, T=T, lang_rows=lang[:B * T], lens=lens[:B])
+            fr = dict(grp["fr"])
+            tag = fr["tag_all"]
+            root = self._root
+            fr.update(upos=tag[0][:B * T].view(B, T)[:, root:], attrs=tag[1][:B * T].view(B, T)[:, root:],
+                      xpos=tag[2][:B * T].view(B, T)[:, root:])
+            r = self._back(vbt, fr, g)
             ev_back = torch.cuda.Event()
             ev_back.record(s2)
         with torch.cuda.stream(s3):
             s3.wait_event(ev_back)
-            r = self._decode(bt, r, slot)
+            r = self._decode(vbt, r, g)
             n = 5 * B * L
-            host = self._host_res[slot]
+            host = grp["host"]
             if host is None or host.numel() < n + B:
                 host = torch.empty(n + B, dtype=torch.int32, pin_memory=True)
-                self._host_res[slot] = host
+                grp["host"] = host
             host[:n].view(5, B, L).copy_(r["packed"], non_blocking=True)
             host[n:n + B].copy_(r["status"], non_blocking=True)
             done = torch.cuda.Event()
             done.record(s3)
-            self._slot_free[slot] = done
-        # the ticket keeps the batch's device inputs alive until `collect`: they were allocated on the
-        # caller's stream, and freeing them earlier would let the next upload reuse their memory
-        # while the kernels of this batch (on the stage streams) still read it
-        return dict(slot=slot, done=done, B=B, L=L, bt=bt)
+        grp.update(done=done, free=done, vbt=vbt, fr=None)
 
     def collect(self, ticket):
         """Wait for a submitted batch: -> (int32 [5, B, L] = heads, labels, upos, xpos, attrs; status [B])."""
-        ticket["done"].synchronize()
+        g = ticket["group"]
+        grp = self._groups[g]
+        if not any(m is ticket for m in grp["members"]):
+            raise hip.CubeHipError("Parser.collect: the ticket is not in flight")
+        if grp["open"]:
+            with torch.cuda.device(self._device):
+                self._close_group(g)  # nobody else is coming: run the group's later stages now
+        grp["done"].synchronize()
         ticket.pop("bt", None)
-        B, L = ticket["B"], ticket["L"]
-        host = self._host_res[ticket["slot"]]
-        n = 5 * B * L
-        out = host[:n].view(5, B, L).numpy().copy(), host[n:n + B].numpy().copy()
-        self._slot_busy[ticket["slot"]] = False  # only now may the slot's next batch overwrite the pinned buffer
+        Bg, L = grp["B"], grp["L"]
+        host = grp["host"]
+        n = 5 * Bg * L
+        b0, b1 = ticket["b_off"], ticket["b_off"] + ticket["B"]
+        out = host[:n].view(5, Bg, L)[:, b0:b1].numpy().copy(), host[n + b0:n + b1].numpy().copy()
+        grp["members"] = [m for m in grp["members"] if m is not ticket]
+        grp["pending"] -= 1  # at zero the group's next batches may overwrite the pinned buffer
+        if not grp["pending"]:
+            grp.pop("vbt", None)
         return out
 
     def _drain(self):
         """Forget batches that were submitted and never collected (an exception between submit and collect):
-        wait for the stage streams, free every slot."""
+        wait for the stage streams, free every group."""
         if self._streams is not None:
             for st in self._streams:
                 st.synchronize()
-            self._slot_busy = [False] * self.N_SLOTS
+            for grp in self._groups:
+                grp.update(pending=0, members=[], open=False, fr=None)
+                grp.pop("vbt", None)
+            self._open = None
         # staging sets that an exception left marked busy (between featurisation and upload): nothing reads them any more
         for st in self.__dict__.get("_staging", ()):
             if st["busy"]:
