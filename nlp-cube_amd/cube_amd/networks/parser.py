@@ -836,6 +836,10 @@ class Parser(_HipNet):
     # batch-independence the parity suite checks), so results do not change; what changes is that the 3 x T serial
     # recurrent steps, the decoder's task waves and a dozen launch-bound small GEMMs are paid once per group.
     PAIR = int(os.environ.get("CUBE_PAIR", "3"))  # batches per group (same sentence length; the later ones no larger than the first)
+    # Grouping pays when the serial chain of stage 2 (3 layers x T recurrent steps of ~4.6 us) outlasts a first stage
+    # (~1.1 ms for 8192 tokens): measured 25k -> 35k sentences/s at T = 129, nothing at T = 33 (the chip-time is the same,
+    # and a group drains later at the end of a short run: 158k -> 152k in a 20-step region).  Below this length: no groups.
+    PAIR_MIN_T = int(os.environ.get("CUBE_PAIR_MIN_T", "64"))
     N_SLOTS = 2 * PAIR + 1   # batches that may be in flight (submitted, not collected)
     N_GROUPS = N_SLOTS       # groups in flight: as many as batches, for when no two consecutive batches share a length
 
@@ -870,7 +874,7 @@ class Parser(_HipNet):
         g = self._open
         if g is not None:
             grp = self._groups[g]
-            if grp["T"] != T or grp["rows"] + B * T > grp["cap"] or len(grp["members"]) >= self.PAIR:
+            if grp["T"] != T or grp["rows"] + B * T > grp["cap"] or len(grp["members"]) >= grp["pair"]:
                 self._close_group(g)
                 g = None
         s1 = self._streams[0]
@@ -883,7 +887,8 @@ class Parser(_HipNet):
             grp = self._groups[g]
             self._n_groups += 1
             grp["serial"] = self._n_groups
-            grp.update(members=[], open=True, T=T, L=L, rows=0, cap=self.PAIR * B * T, done=None, B=0)
+            pair = self.PAIR if T >= self.PAIR_MIN_T else 1
+            grp.update(members=[], open=True, T=T, L=L, rows=0, cap=pair * B * T, done=None, B=0, pair=pair)
             self._open = g
             if grp["free"] is not None:
                 s1.wait_event(grp["free"])  # the later stages of the group that used these buffers last
@@ -898,7 +903,7 @@ class Parser(_HipNet):
         ticket = dict(group=g, serial=self._n_groups, b_off=grp["B"], B=B, L=L, bt=bt)
         grp["members"].append(ticket)
         grp.update(rows=grp["rows"] + B * T, B=grp["B"] + B, fr=fr, ev_front=ev_front, pending=grp["pending"] + 1)
-        if len(grp["members"]) >= self.PAIR:
+        if len(grp["members"]) >= grp["pair"]:
             self._close_group(g)
         return ticket
 

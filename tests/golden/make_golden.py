@@ -229,6 +229,27 @@ def g6_arcs():
     np.savez_compressed(os.path.join(HERE, "g6_process_arcs.npz"), **save)
 
 
+def g0_config0():
+    """BASELINE configs[0] / SURVEY 8d config 0 at its stated size: 1000 synthetic sentences x 20 tokens, seed 0, through
+    the reference's whole boundary -- Document in, `Parser.process` (batch_size 32), CoNLL-U text out -- plus the arc
+    scores of every batch `process` forms (for the near-tie rule of the GPU test)."""
+    p, cfg, enc, sd = build_ref_parser(cases.FULL)
+    col = REF["MorphoCollate"](ref_encodings(enc))
+    doc = ref_document(synth.make_document(enc, [20] * 1000, seed=0, ext_word_emb=(300,)))
+    arcs = {}
+    bs = 32
+    for start in range(0, len(doc.sentences), bs):
+        batch = col.collate_fn(doc.sentences[start:start + bs])
+        del batch["y_upos"]
+        with torch.no_grad():
+            arcs["%d" % start] = p.forward(batch)[0].numpy().astype(np.float32)
+    p.process(doc, col, batch_size=bs, num_workers=0)
+    with open(os.path.join(HERE, "g0_config0_1000x20_bs32.conllu"), "w", encoding="utf-8") as f:
+        f.write(str(doc))
+    np.savez_compressed(os.path.join(HERE, "g0_config0_arcs.npz"), **arcs)
+    print("g0", len(doc.sentences), "sentences")
+
+
 def g7_tagger():
     save = {}
     for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
@@ -338,7 +359,9 @@ def g9_lemmatizer():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g6a", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g6", "g6a", "g7", "g8", "g9", "g10", "g11"]
+    if "g0" in which:
+        g0_config0()
     if "g1" in which:
         g1_collate()
     if "g2" in which:

@@ -94,6 +94,29 @@ def test_g6_process_text_matches_reference(golden_dir, case, tag, bs):
         assert len(gl) == len(el) and len(diff) <= 0, (len(diff), gl[diff[0]], el[diff[0]])
 
 
+def test_g0_config0_first_batches_match_reference(golden_dir):
+    """BASELINE configs[0] (1000 sentences x 20 tokens, seed 0, batch_size 32, CPU): the oracle's `process` text of the
+    first three reference batches (96 sentences; the whole document is the GPU test's, this one stays within the CPU
+    suite's minutes) equals the text the reference produced (G0); arc scores of those batches to fp32 tolerance."""
+    from cube_amd import synth
+    from cube_amd.io_utils.objects import Document
+    cfg, enc, sd = cases.parser_model(cases.FULL)
+    net = parser_oracle.OracleParser(cfg, enc, sd, [300], quant="fp32")
+    torch.set_num_threads(8)
+    full = synth.make_document(enc, [20] * 1000, seed=0, ext_word_emb=(300,))
+    doc = Document()
+    doc.sentences = full.sentences[:96]
+    arcs = np.load(os.path.join(golden_dir, "g0_config0_arcs.npz"))
+    with torch.no_grad():
+        att = net.forward(parser_oracle.collate(doc.sentences[32:64], enc))[0].numpy()
+    np.testing.assert_allclose(att, arcs["32"], **FP32_TOL)
+    net.process(doc, batch_size=32)
+    with open(os.path.join(golden_dir, "g0_config0_1000x20_bs32.conllu"), encoding="utf-8") as f:
+        exp = f.read().split("\n\n")[:96]
+    got = str(doc).split("\n\n")[:96]
+    assert len(exp) == 96 and [g.strip("\n") for g in got] == [e.strip("\n") for e in exp]
+
+
 def test_g7_tagger_matches_reference(golden_dir):
     g = _load(golden_dir, "g7_tagger.npz")
     for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
