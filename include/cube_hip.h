@@ -18,6 +18,7 @@
  *   cube_split_f32          the fp32 -> operand-plane cast of the external embeddings (parser.py:130-136)
  *   cube_ext_finish         word_emb_ext / K, tanh (parser.py:137-138,195-197; tagger.py:118-119)
  *   cube_argmax_rows        torch.argmax over tag/label logits (parser.py:186,428-431)
+ *   cube_subword_pool       sub-word -> word averaging of LMHelperHF._compute_we / apply (lm.py:183-208)
  *   cube_bilstm_recurrent[_i8]  torch.lstm recurrence, 1 layer, both directions (parser.py:201)
  *   cube_biaffine_arc       PairwiseBilinear bmm + torch.softmax (modules.py:518-533;
  *                           parser.py:214-216,425)
@@ -190,6 +191,18 @@ int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int root, int P,
  * an fp32 tensor — the external embeddings of a batch (parser.py:130-131: x_word_embeddings arrive as fp32
  * from the LM helper, lm.py:199-208).  n % 4 == 0.                                                        */
 int cube_split_f32(const float* x, size_t n, void* hi, void* lo, void* stream);
+
+/* Sub-word piece -> word pooling of the external-embedding stage: LMHelperHF._compute_we (lm.py:183-197) and the cut
+ * into per-layer vectors of LMHelperHF.apply (lm.py:199-208), on hidden states that are on the device.
+ * hidden: HOST array of n_layers device pointers (<= CUBE_POOL_MAX_LAYERS), layer k f32 [sentences, pieces, E] with
+ * strides stride_s / stride_p (floats); word w covers the word_n[w] consecutive pieces from (word_sent[w], word_pos[w]).
+ * out f32 [n_layers, n_words, E]: n = 0 -> zeros; n = 1 -> the piece; n >= 2 -> ((h0 + h0) + h1 + ... + h(n-2)) / n --
+ * the reference's loop adds the first piece to itself in place and never reaches the last one.  fp32, additions in
+ * that order, IEEE division: bit-equal to the reference's NumPy arithmetic.  E, strides % 4 == 0.             */
+#define CUBE_POOL_MAX_LAYERS 32
+int cube_subword_pool(const void* const* hidden, int n_layers, size_t stride_s, size_t stride_p, int E,
+                      const int32_t* word_sent, const int32_t* word_pos, const int32_t* word_n, int n_words,
+                      float* out, void* stream);
 
 /* out[r] = first index of the maximum of x[r, col0 .. col0+n)   (x f32 [M, ld])             */
 int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream);

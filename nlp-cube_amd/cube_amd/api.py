@@ -23,7 +23,7 @@ from cube_amd.io_utils.config import LemmatizerConfig, ParserConfig, TokenizerCo
 from cube_amd.io_utils.encodings import Encodings
 from cube_amd.io_utils.objects import Document
 from cube_amd.networks.lemmatizer import Lemmatizer, Word2TargetCollate
-from cube_amd.networks.lm import LMHelperDummy, LMHelperPrecomputed
+from cube_amd.networks.lm import LMHelperDummy, LMHelperHF, LMHelperPrecomputed
 from cube_amd.networks.parser import Parser
 from cube_amd.networks.tokenizer import Tokenizer
 from cube_amd.networks.utils import MorphoCollate
@@ -69,9 +69,13 @@ class CubeObj:
             self._lm_helper = lm_helper
         elif str(config.lm_model).startswith("dummy"):
             self._lm_helper = LMHelperDummy()
+        elif str(config.lm_model).startswith("transformer"):
+            # reference: api.py:95-96.  The name after ':' goes to transformers' from_pretrained as in the reference; offline
+            # it must be a local directory (or pass lm_helper=LMHelperHF(device, splitter=..., encoder=...) with loaded objects)
+            self._lm_helper = LMHelperHF(device=device, model=str(config.lm_model).split(":")[-1])
         else:
             raise NotImplementedError(
-                "lm_model '%s' needs an external embedding model (out of scope, SURVEY.md §8f); pass "
+                "lm_model '%s' needs a fastText model (api.py:97-98; not rebuilt, SURVEY.md §8f); pass "
                 "lm_helper=LMHelperPrecomputed(sizes) and set word.emb yourself" % config.lm_model)
         encodings = Encodings()
         encodings.load("{0}.encodings".format(path))

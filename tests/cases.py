@@ -176,3 +176,55 @@ def mst_cases():
     p[0, :, 0] = 0.0
     out["notree_L5"] = (p.astype(np.float32), np.full(1, L, np.int64))
     return out
+
+
+# ---- external-embedding stage: stand-ins for the tokenizer / transformer objects that LMHelperHF holds
+# (lm.py:122-135; the real ones need model files that cannot be fetched).  Deterministic from seeds, so that the
+# reference's own `_compute_we` / `apply` (tests/golden/make_golden.py g12) and this repo's see the same hidden states.
+LM_LAYERS, LM_WIDTH, LM_PIECES = 13, 768, 1000   # lm.py:193,206-207 hard-code 13 x 768
+
+
+class FakeSplitter:
+    """`splitter(word)['input_ids']` = [START] + pieces + [END] (lm.py:155): 0..5 pieces per word from a CRC of the word."""
+
+    def __call__(self, word):
+        import zlib
+        h = zlib.crc32(word.encode("utf-8"))
+        n = 0 if word.startswith("\u200b") else 1 + (h % 5 if h % 7 else 0)
+        return {"input_ids": [0] + [3 + (h >> (3 * j)) % (LM_PIECES - 3) for j in range(n)] + [2]}
+
+
+class FakeEncoder:
+    """`model(x, return_dict=True)['hidden_states']`: K tensors [B, len, E], value = table_k[id] + 0.1 * pos_k[position in
+    the window it was called with] -- like the real model, a window's output depends on the window alone (lm.py:177-181)."""
+
+    def __init__(self, seed=7, device="cpu"):
+        import torch
+        g = torch.Generator().manual_seed(seed)
+        self.tok = [torch.randn((LM_PIECES, LM_WIDTH), generator=g) for _ in range(LM_LAYERS)]
+        self.pos = [torch.randn((512, LM_WIDTH), generator=g) for _ in range(LM_LAYERS)]
+        self.device = device
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.tok = [t.to(device) for t in self.tok]
+        self.pos = [t.to(device) for t in self.pos]
+        self.device = device
+        return self
+
+    def __call__(self, x, return_dict=True):
+        hs = tuple(t[x] + 0.1 * p[:x.shape[1]].unsqueeze(0) for t, p in zip(self.tok, self.pos))
+        return {"hidden_states": hs}
+
+
+def lm_document(enc):
+    """three short sentences, one of a single word, one word without pieces, and a sentence of 220 words whose ~580 pieces
+    cross the 512-piece window of lm.py:171-181"""
+    doc = synth.make_document(enc, [5, 1, 12, 220], seed=4242, ext_word_emb=(4,))
+    doc.sentences[2].words[3].word = "\u200bnothing"
+    for s in doc.sentences:
+        for w in s.words:
+            w.emb = None
+    return doc

@@ -250,6 +250,26 @@ def g0_config0():
     print("g0", len(doc.sentences), "sentences")
 
 
+def g12_lm_pooling():
+    """The reference's own sub-word -> word pooling, `LMHelperHF.apply` -> `_compute_we` (lm.py:141-208), driven with the
+    synthetic tokenizer / transformer stand-ins of tests/cases.py (the real ones need model files): the 13 x 768 values
+    of every word of the three short sentences, every 16th value for the 220-word sentence (two 512-piece windows)."""
+    from cube.networks.lm import LMHelperHF
+    _, enc, _ = cases.parser_model(cases.FULL)
+    h = LMHelperHF.__new__(LMHelperHF)          # no from_pretrained: the members __init__ would have set (lm.py:122-135)
+    h._splitter, h._xlmr, h._device = cases.FakeSplitter(), cases.FakeEncoder(), "cpu"
+    h._emb_size = [cases.LM_WIDTH] * cases.LM_LAYERS
+    doc = ref_document(cases.lm_document(enc))
+    h.apply(doc)
+    save = {}
+    for i, s_ in enumerate(doc.sentences):
+        a = np.stack([np.stack([np.asarray(v) for v in w.emb]) for w in s_.words])   # [words, 13, 768]
+        save["sent%d" % i] = a.astype(np.float32) if i < 3 else a[:, :, ::16].astype(np.float32)
+        save["dtype%d" % i] = np.array(str(np.asarray(s_.words[0].emb[0]).dtype))
+    np.savez_compressed(os.path.join(HERE, "g12_lm_pooling.npz"), **save)
+    print("g12", {k: v.shape for k, v in save.items()})
+
+
 def g7_tagger():
     save = {}
     for case, tag in ((cases.TINY_TAGGER, "tiny"), (cases.FULL_TAGGER, "full")):
@@ -359,7 +379,7 @@ def g9_lemmatizer():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g6", "g6a", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g6", "g6a", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g0" in which:
         g0_config0()
     if "g1" in which:
@@ -384,3 +404,5 @@ if __name__ == "__main__":
         g10_tokenizer()
     if "g11" in which:
         g11_bench_batches()
+    if "g12" in which:
+        g12_lm_pooling()
