@@ -210,8 +210,11 @@ static inline double now_s(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* Grow-only scratch buffers of featurize.  The call holds the GIL from start to end, so it cannot overlap itself;
- * keeping the buffers avoids a dozen malloc / mmap / page-fault / munmap rounds of 64..800 KB per batch. */
+/* Grow-only scratch buffers of featurize: keeping them avoids a dozen malloc / mmap / page-fault / munmap rounds of
+ * 64..800 KB per batch.  The call holds the GIL, but Python code can still run inside it (a Word class with properties or
+ * __getattr__, finalisers run by an allocation) and switch to a thread that calls featurize again: `g_sc_busy` turns
+ * that second call away (TypeError -> the caller's Python featurisation) instead of letting it realloc these buffers. */
+static int g_sc_busy;
 enum { SC_SLOTS = 20 };
 static void* g_sc[SC_SLOTS];
 static size_t g_sc_cap[SC_SLOTS];
@@ -297,6 +300,11 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     PyErr_SetString(PyExc_ValueError, "featurize: bad n_layers / root / L / embedding arguments");
     return NULL;
   }
+  if (g_sc_busy) {
+    PyErr_SetString(PyExc_TypeError, "featurize: re-entered while another call is using its scratch buffers");
+    return NULL;
+  }
+  g_sc_busy = 1;
   const Py_ssize_t top = PyArray_DIM(cp_tab, 1);
   const int32_t* tab_char = (const int32_t*)PyArray_DATA(cp_tab);
   const int32_t* tab_case = tab_char + top;
@@ -425,8 +433,11 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         if (K > 0) __builtin_prefetch(wel[w + PF]);
       }
       PyObject* t = wstr[w];
-      if (!PyUnicode_Check(t) || PyUnicode_READY(t) != 0) {
-        PyErr_Format(PyExc_ValueError, "featurize: word %d of sentence %d is not a str", (int)si[w], (int)sb[w]);
+      if (!PyUnicode_CheckExact(t) || PyUnicode_READY(t) != 0) {
+        /* a str subclass could run Python code in .lower() / __hash__ / __eq__ below: not the fast format (TypeError ->
+         * the caller's Python featurisation); anything else is an error of the document */
+        if (PyUnicode_Check(t)) PyErr_Format(PyExc_TypeError, "featurize: word %d of sentence %d is a str subclass", (int)si[w], (int)sb[w]);
+        else PyErr_Format(PyExc_ValueError, "featurize: word %d of sentence %d is not a str", (int)si[w], (int)sb[w]);
         bad = 1;
         break;
       }
@@ -730,6 +741,7 @@ done:
   if (have_ibuf) PyBuffer_Release(&ibuf);
   for (Py_ssize_t k = 0; k < n_ebuf; ++k) PyBuffer_Release(&ebuf[k]);
   if (wemb) for (Py_ssize_t w = 0; w < n_wemb; ++w) Py_XDECREF(wemb[w]);
+  g_sc_busy = 0;
   return result;
 }
 

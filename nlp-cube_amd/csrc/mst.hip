@@ -43,6 +43,9 @@ namespace {
 // per workgroup the 256 first-pass workgroups land on 256 different CUs, 11 KB of LDS each, and no CU can take a GEMM
 // tile until they are done.  Packed, the same tasks sit on B / 14 CUs (L = 32) and leave the rest of the chip alone.
 constexpr int MST_MAX_WAVES = 16;
+// the rooted re-runs need ~160 registers: 12 waves per workgroup (three per SIMD, 168 registers each) keep them out of scratch
+// memory -- with 16 the compiler had 128 and spilled 40 bytes per lane, a private-segment allocation at first dispatch
+constexpr int MST_ROOT_MAX_WAVES = 12;
 constexpr int MST_ROOT_MAX_BLOCKS = 96;  // CUs the rooted re-runs may spread over when tasks are packed
 constexpr int MST_BOUND_MIN_CAND = 4;    // up to this many candidate roots of a sentence all run in the first round (mst_first_kernel)
 
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_first_kernel
 }
 
 template <bool GS, typename IdT, bool GREC>
-__global__ __launch_bounds__(GS ? 64 : 64 * MST_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
+__global__ __launch_bounds__(GS ? 64 : 64 * MST_ROOT_MAX_WAVES) void mst_root_kernel(const float* __restrict__ probs,
                                                                       const int32_t* __restrict__ lens, int B, int L, MstWs ws,
                                                                       int lds_task, int phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -791,12 +794,12 @@ int mst_launch(const float* probs, const int32_t* lens, int B, int L, int32_t* h
   const size_t task_first = (mst_lds_bytes(L + 1, GS_FIRST, ID, GREC_FIRST) + 15) & ~(size_t)15;
   const size_t task_root = (mst_lds_bytes(L + 1, GS_ROOT, ID, GREC_ROOT) + 15) & ~(size_t)15;
   // tasks per workgroup: as many as the CU's LDS holds (workspace-resident matrices: one, their blocks index the workspace)
-  auto waves = [](size_t task, bool gs) {
+  auto waves = [](size_t task, bool gs, int most) {
     if (gs) return 1;
     const size_t w = ((size_t)160 * 1024) / task;
-    return (int)(w < 1 ? 1 : (w > (size_t)MST_MAX_WAVES ? (size_t)MST_MAX_WAVES : w));
+    return (int)(w < 1 ? 1 : (w > (size_t)most ? (size_t)most : w));
   };
-  const int w_first = waves(task_first, GS_FIRST), w_root = waves(task_root, GS_ROOT);
+  const int w_first = waves(task_first, GS_FIRST, MST_MAX_WAVES), w_root = waves(task_root, GS_ROOT, MST_ROOT_MAX_WAVES);
   const size_t lds_first = task_first * w_first, lds_root = task_root * w_root;
   static CubeLdsReservation reserved[2];
   if (!reserved[0].ensure((const void*)mst_first_kernel<GS_FIRST, IdT, GREC_FIRST>, lds_first) ||

@@ -383,6 +383,18 @@ def test_c_featurizer_equals_collate_plus_prepare(which):
     assert p._featurize(list(doc.sentences[:2]), col) is None
     h = p._host_batch(list(doc.sentences[:2]), col)
     assert h["B"] == 2
+    # a str subclass may run Python code in .lower() / __hash__: not the fast format either, same arrays through Python
+    class Shout(str):
+        def lower(self):
+            return str.lower(self)
+    doc2 = cases.document(case, enc, "g6")
+    ref = p._host_batch(list(doc2.sentences[4:7]), col)
+    ref = dict(packed=ref["packed"].copy(), st=p._staging_release(ref["staging"]))
+    doc2.sentences[5].words[1].word = Shout(doc2.sentences[5].words[1].word)
+    assert p._featurize(list(doc2.sentences[4:7]), col) is None
+    assert not any(st["busy"] for st in p._staging)
+    h2 = p._host_batch(list(doc2.sentences[4:7]), col)
+    np.testing.assert_array_equal(np.sort(h2["packed"]), np.sort(ref["packed"]))
 
 
 def test_featurizer_errors_give_their_staging_set_back():
