@@ -54,24 +54,45 @@ def _batch(enc, dk, n):
     return Word2TargetCollate(enc).collate_fn([ds[i] for i in range(min(n, len(ds)))], targets=False)
 
 
-def _compare_sequences(got_c, got_k, ref_c, ref_k, margin_logits, max_bad_frac, margin_steps=1 << 30):
-    """identical, or different from a step whose top-2 margin (in margin_logits [B, n, C]) is tiny
-    (checked for first differences before step `margin_steps`)."""
+ROUNDOFF_RATIO = 2.0 ** 7   # unit round-off of the bf16x3 operands (2^-17) over that of the reference's fp32 (2^-24)
+
+
+def _compare_sequences(got_logits, got_k, ref_c, ref_k, l32, l64):
+    """Greedy arg-max histories (from the HIP path's logits [words, steps, C]) against the reference's `ref_c`.  A word may
+    differ only where north_star lets a decision differ:
+    (a) the fp32 oracle's top-2 margin at the FIRST differing step t is below 1e-3 of the logit scale (a near-tie), or
+    (b) the word's history is decided by round-off: up to step t the HIP path's logits deviate from the fp32 oracle's
+        (same history) by no more than 2 x ROUNDOFF_RATIO x what the oracle's OWN arithmetic is uncertain by there -- the
+        largest difference between its fp32 and float64 runs (`l32`, `l64`) over the steps <= t.  The fed-back decoder of
+        a random-init model is chaotic for the words that never emit the stop symbol: every round-off grows by the same
+        factor (measured: x 3000 in 60 steps, for the fp32 oracle against float64 exactly as for the HIP path against
+        the fp32 oracle, a constant ratio of ~75 between the two), so this bounds the implementation's precision at its
+        16-17 bits without pretending that the 1e-3 score tolerance survives hundreds of fed-back steps.
+    Everything else must be identical; no count of tolerated words.  -> (differing words, of them by rule b)."""
+    got_c = got_logits.argmax(-1)
     assert got_c.shape == ref_c.shape, (got_c.shape, ref_c.shape)
     same = got_c == ref_c
     bad = np.where(~same.all(1))[0]
-    assert len(bad) <= max_bad_frac * len(same), (len(bad), len(same))
+    n_b = 0
     for w in bad:
         t = int(np.argmin(same[w]))
-        if t < margin_logits.shape[1]:
-            top = np.sort(margin_logits[w, t].astype(np.float64))[-2:]
-            print("word %d differs from step %d: top-2 margin %.3g (logit scale %.3g)"
-                  % (w, t, top[1] - top[0], np.abs(margin_logits[w, t]).max()))
-            assert t >= margin_steps or top[1] - top[0] < REL_TOL * max(1.0, float(np.abs(margin_logits[w, t]).max())), (w, t, top)
+        top = np.sort(l32[w, t].astype(np.float64))[-2:]
+        scale = max(1.0, float(np.abs(l32[w, t]).max()))
+        near_tie = top[1] - top[0] < REL_TOL * scale
+        msg = ""
+        if not near_tie:
+            n = min(t + 1, l64.shape[1])
+            sc = np.maximum(np.abs(l32[w, :n]).max(axis=-1), 1.0)
+            e_ref = float((np.abs(l64[w, :n] - l32[w, :n]).max(axis=-1) / sc).max())
+            e_dev = float((np.abs(got_logits[w, :n] - l32[w, :n]).max(axis=-1) / sc).max())
+            msg = "; deviation %.2g = %.0f x the oracle's own fp32 / float64 difference %.2g" % (e_dev, e_dev / e_ref, e_ref)
+            assert n == t + 1 and e_dev <= 2 * ROUNDOFF_RATIO * e_ref, (int(w), t, top.tolist(), e_dev, e_ref)
+            n_b += 1
+        print("word %d differs from step %d: top-2 margin %.3g (logit scale %.3g)%s" % (w, t, top[1] - top[0], scale, msg))
     ok = same.all(1)
     # the case head (4 logits per step, not fed back) has near-ties of its own
     assert (got_k[ok] != ref_k[ok]).mean() <= 1e-3
-    return len(bad)
+    return len(bad), n_b
 
 
 def test_collate_matches_reference_golden(g9):
@@ -133,11 +154,10 @@ def test_forward_matches_reference_golden(dev, g9, tag, dk, n):
     from oracle import lemmatizer_oracle as lo
     oc_all = lo.OracleLemmatizer(cfg, enc, sd).forward(X)[0].numpy()
     assert np.array_equal(oc_all.argmax(-1), ref_c) or tag == "small"
-    # (the small model is close to chaotic: the fp32 and fp64 oracles already part after ~200 steps in 2 of
-    # 128 words, at margins of 3e-3 .. 6e-2, so its margin rule covers the first 64 steps only)
-    nbad = _compare_sequences(got_c, got_k, ref_c, ref_k, oc_all, max_bad_frac=0.04 if tag == "full" else 0.07,  # measured: 1/37, 4/128; 1/37, 7/128
-                              margin_steps=1 << 30 if tag == "full" else 64)
-    print("%s/%s: %d of %d words differ from the reference (near-ties)" % (tag, dk, nbad, len(ref_c)))
+    l64 = lo.OracleLemmatizer(cfg, enc, sd, dtype=torch.float64).forward(X)[0].numpy() if (got_c != ref_c).any() else oc_all
+    nbad, n_chaotic = _compare_sequences(yc, got_k, ref_c, ref_k, oc_all, l64)
+    print("%s/%s: %d of %d words differ from the reference (%d near-ties, %d decided by round-off)"
+          % (tag, dk, nbad, len(ref_c), nbad - n_chaotic, n_chaotic))
 
 
 @pytest.mark.parametrize("tag,bs", [("full", 32), ("full", 4), ("small", 32)])
@@ -152,11 +172,40 @@ def test_process_matches_reference_golden(dev, golden_dir, tag, bs):
     with open(os.path.join(golden_dir, "g9_lemmas_%s_bs%d.txt" % (tag, bs)), encoding="utf-8") as f:
         ref = f.read().split("\n")[:-1]
     assert len(got) == len(ref)
-    bad = sum(a != b for a, b in zip(got, ref))
-    # words that run into the 20*S failsafe accumulate bf16x3 rounding over hundreds of fed-back steps
-    # and may leave the reference's limit cycle at a near-tie (see test_forward_matches_reference_golden)
-    print("%s bs%d: %d of %d lemmas differ" % (tag, bs, bad, len(ref)))
-    assert bad <= (0.01 if tag == "full" else 0.025) * len(ref), bad  # measured: 3 / 3 / 7 of 384
+    bad = [i for i, (a, b) in enumerate(zip(got, ref)) if a != b]
+    print("%s bs%d: %d of %d lemmas differ" % (tag, bs, len(bad), len(ref)))
+    if not bad:
+        return
+    # A lemma that differs is held to the rule of `_compare_sequences` in the reference batch it was decoded in (in-order
+    # batches of `bs` words, lemmatizer.py:189-193): near-tie at the first differing step, or a word the float64 oracle
+    # shows to be decided by round-off.  No count of tolerated lemmas.
+    from oracle import lemmatizer_oracle as lo
+    from cube_amd.networks.lemmatizer import LemmaDataset
+    ds = LemmaDataset(cases.lemma_document(enc, "g6", max_word_len=6), for_training=False)
+    col = Word2TargetCollate(enc)
+    o32 = lo.OracleLemmatizer(cfg, enc, sd)
+    for a in sorted({i // bs * bs for i in bad}):
+        ids = list(range(a, min(a + bs, len(ds))))
+        X = col.collate_fn([ds[i] for i in ids], targets=False)
+        yc, yk = m.forward(X)
+        yc, yk = yc.cpu().numpy(), yk.cpu().numpy()
+        oc, ok = yc.argmax(-1), yk.argmax(-1)
+        strings = m._strings(oc, ok)
+        assert [ds[i]["word"] + "\t" + sl for i, sl in zip(ids, strings)] == [got[i] for i in ids]   # process == this batch decoded
+        l32, k32 = (t.numpy() for t in o32.forward(X))
+        ref_c = l32.argmax(-1)
+        assert oc.shape == ref_c.shape
+        # the fp32 oracle IS the reference on this batch: its strings are the stored ones
+        ref_strings = m._strings(ref_c, k32.argmax(-1))
+        l64 = lo.OracleLemmatizer(cfg, enc, sd, dtype=torch.float64).forward(X)[0].numpy()
+        n64 = min(l64.shape[1], ref_c.shape[1])
+        keep = []
+        for j, (i, r) in enumerate(zip(ids, ref_strings)):
+            if ds[i]["word"] + "\t" + r == ref[i]:
+                keep.append(j)
+            else:   # (the oracle's own BLAS order already leaves the stored text: float64 must show the word undecided too)
+                assert (l64[j, :n64].argmax(-1) != ref_c[j, :n64]).any(), (a, j)
+        _compare_sequences(yc[keep], ok[keep], ref_c[keep], ok[keep], l32[keep], l64[keep])
 
 
 def test_bf16_single_pass_mode_runs_and_mostly_agrees(dev, g9):
@@ -185,7 +234,7 @@ def test_long_words_and_single_word_batches(dev):
         oc, ok = m.decode_batch(X)
         yc, yk = orc.forward(X)
         rc, rk = yc.argmax(-1).numpy(), yk.argmax(-1).numpy()
-        _compare_sequences(oc, ok, rc, rk, yc.numpy(), max_bad_frac=0.0)
+        assert np.array_equal(oc, rc) and np.array_equal(ok, rk)
     doc.sentences[0].words[0].word = "x" * 26
     with pytest.raises(IndexError):
         m.process(doc, col, batch_size=8)
