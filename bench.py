@@ -102,7 +102,7 @@ def run_steps(p, batches, n, serial=False):
     inflight = deque()
     for i in range(n):
         inflight.append(p.submit(batches[i % len(batches)]))
-        if len(inflight) == p.N_SLOTS:  # host runs N_SLOTS - 1 batches ahead of the one it waits for
+        if len(inflight) >= p.in_flight_for(batches[0]["T"]):  # the host runs that many batches ahead of the one it waits for
             out = p.collect(inflight.popleft())
     while inflight:
         out = p.collect(inflight.popleft())
@@ -126,7 +126,7 @@ def run_corpus_pass(p, batches, reps, ids, n_words_base):
     for rep in range(reps):
         for bt in batches:
             inflight.append((rep, bt, p.submit(bt)))
-            if len(inflight) == p.N_SLOTS:
+            if len(inflight) >= p.in_flight_for(bt["T"]):
                 bad += retire()
     while inflight:
         bad += retire()

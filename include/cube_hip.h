@@ -125,6 +125,29 @@ int cube_gemm_bf16(const cube_gemm_args* args, void* stream);
 int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, const void* table, const void* table_lo,
                      int ld_table, const int32_t* idx, const int32_t* dst_rows, int n, void* stream);
 
+/* Up to CUBE_GATHER_BATCH_MAX cube_gather_rows in ONE launch (the embedding look-ups and concatenations of one stage that
+ * depend on the batch's index arrays only: parser.py:140-156,172-175,180-183).  descs: HOST array.  The gathers must not
+ * write the same elements (no ordering between them).                                                               */
+#define CUBE_GATHER_BATCH_MAX 8
+typedef struct {
+  void* dst; void* dst_lo; int ld_dst; int col0; int width;
+  const void* table; const void* table_lo; int ld_table;
+  const int32_t* idx; const int32_t* dst_rows; int n;
+} cube_gather_desc;
+int cube_gather_rows_batch(const cube_gather_desc* descs, int n_desc, void* stream);
+
+/* Tag decisions of a row in one launch (parser.py:186-192, 428-431): out_a[r] = first maximum of x[r, col_a .. col_a+n_a),
+ * out_b[r] likewise for a second range (out_b may be NULL), and -- when dst is given -- the embedding row table[out_a[r]]
+ * (width values, bf16 planes) into dst[r, col_dst .. col_dst+width): UPOS arg-max + _upos_emb look-up (parser.py:186-190),
+ * or the ATTRS and XPOS arg-maxes over the two halves of one logits matrix.                                          */
+int cube_tag_argmax(const float* x, int ld, int M, int col_a, int n_a, int32_t* out_a, int col_b, int n_b, int32_t* out_b,
+                    const void* table, const void* table_lo, int ld_table, int width, void* dst, void* dst_lo, int ld_dst,
+                    int col_dst, void* stream);
+
+/* tags int32 [3, cap] = (upos, attrs, xpos) decisions of B*T positions (root rows included when root = 1) ->
+ * out int32 [3, B, T-root] = (upos, xpos, attrs) of the words: rows 2..4 of the result array (parser.py:428-431).    */
+int cube_pack_tags(const int32_t* tags, int cap, int B, int T, int root, int32_t* out, void* stream);
+
 /* WordGram tail: out[n, c] = bf16( sum_k weight[k] * sum_{p < len[n]} x_k[n*W + p, c] / max(len[n], 1) )
  * over the n_layers gated-layer outputs x_k (bf16 [N*W, ld_x], hi [+ lo] planes); x_hi / x_lo /
  * weight are HOST arrays of n_layers entries (x_lo may be NULL).  With weight = 1,..,1,2 this is

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 15; }
+extern "C" int cube_abi_version(void) { return 16; }
 
 namespace {
 
@@ -333,6 +333,148 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld
 }
 
 }  // namespace
+
+// ---- several gathers / arg-maxes of one stage in one launch (each was a 5 us launch of its own on the stage's stream)
+namespace {
+struct GatherBatch {
+  cube_gather_desc d[CUBE_GATHER_BATCH_MAX];
+  int vec_ok[CUBE_GATHER_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(256) void gather_rows_batch_kernel(GatherBatch gb) {
+  const cube_gather_desc& g = gb.d[blockIdx.y];
+  uint16_t* dst = (uint16_t*)g.dst;
+  uint16_t* dst_lo = (uint16_t*)g.dst_lo;
+  const uint16_t* table = (const uint16_t*)g.table;
+  const uint16_t* table_lo = (const uint16_t*)g.table_lo;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < g.n; i += nwaves) {
+    const int src_row = g.idx ? g.idx[i] : 0;
+    const int dst_row = g.dst_rows ? g.dst_rows[i] : i;
+    if (dst_row < 0) continue;
+    const size_t so = (size_t)src_row * g.ld_table, dof = (size_t)dst_row * g.ld_dst + g.col0;
+    if (gb.vec_ok[blockIdx.y]) {
+      for (int c = lane * 8; c < g.width; c += 64 * 8) {
+        *reinterpret_cast<uint4*>(dst + dof + c) = *reinterpret_cast<const uint4*>(table + so + c);
+        if (dst_lo) *reinterpret_cast<uint4*>(dst_lo + dof + c) = *reinterpret_cast<const uint4*>(table_lo + so + c);
+      }
+    } else {
+      for (int c = lane; c < g.width; c += 64) {
+        dst[dof + c] = table[so + c];
+        if (dst_lo) dst_lo[dof + c] = table_lo[so + c];
+      }
+    }
+  }
+}
+
+// one wave per row: first maximum of x[row, col0 .. col0+n)  (NaN counts as maximal, as torch.argmax)
+__device__ __forceinline__ int wave_argmax(const float* p, int n, int lane) {
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < n; c += 64) {
+    const float v = p[c];
+    if (v > best || (v != v && best == best)) { best = v; bi = c; }
+  }
+  if (bi == 0x7fffffff && lane < n) bi = lane;  // all -inf in this lane's slice
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    const bool take = (ob > best) || (ob == best && oi < bi) || (ob != ob && best == best) ||
+                      (ob != ob && best != best && oi < bi);
+    if (take) { best = ob; bi = oi; }
+  }
+  return bi == 0x7fffffff ? 0 : bi;
+}
+
+__global__ __launch_bounds__(256) void tag_argmax_kernel(const float* x, int ld, int M, int col_a, int n_a, int32_t* out_a,
+                                                         int col_b, int n_b, int32_t* out_b, const uint16_t* table,
+                                                         const uint16_t* table_lo, int ld_table, int width, uint16_t* dst,
+                                                         uint16_t* dst_lo, int ld_dst, int col_dst) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* p = x + (size_t)row * ld;
+  const int ia = wave_argmax(p + col_a, n_a, lane);
+  if (lane == 0) out_a[row] = ia;
+  if (out_b) {
+    const int ib = wave_argmax(p + col_b, n_b, lane);
+    if (lane == 0) out_b[row] = ib;
+  }
+  if (dst) {  // the embedding of the first decision into the row's columns [col_dst, col_dst + width)
+    const size_t so = (size_t)ia * ld_table, dof = (size_t)row * ld_dst + col_dst;
+    for (int c = lane; c < width; c += 64) {
+      dst[dof + c] = table[so + c];
+      if (dst_lo) dst_lo[dof + c] = table_lo[so + c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_tags_kernel(const int32_t* tags, int cap, int B, int T, int root, int32_t* out) {
+  const int L = T - root;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * L) return;
+  const int b = t / L, i = t - b * L;
+  const int src = b * T + i + root;
+  out[t] = tags[src];                              // upos
+  out[(size_t)B * L + t] = tags[2 * (size_t)cap + src];      // xpos
+  out[2 * (size_t)B * L + t] = tags[(size_t)cap + src];      // attrs
+}
+}  // namespace
+
+extern "C" int cube_gather_rows_batch(const cube_gather_desc* descs, int n_desc, void* stream) {
+  CUBE_ENTRY();
+  if (n_desc <= 0) return CUBE_OK;
+  if (!descs || n_desc > CUBE_GATHER_BATCH_MAX) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows_batch: %d gathers (1..%d)", n_desc, CUBE_GATHER_BATCH_MAX);
+  GatherBatch gb;
+  int n_max = 0;
+  for (int k = 0; k < n_desc; ++k) {
+    const cube_gather_desc& g = descs[k];
+    if (g.n < 0 || g.width <= 0 || !g.dst || !g.table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows_batch: gather %d: null pointer or bad size", k);
+    if (g.dst_lo && !g.table_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows_batch: gather %d: dst_lo needs table_lo", k);
+    if (g.col0 < 0 || g.col0 + g.width > g.ld_dst || g.width > g.ld_table) CUBE_FAIL(CUBE_ERR_ARG, "cube_gather_rows_batch: gather %d: bad columns", k);
+    gb.d[k] = g;
+    if (!g.dst_lo) gb.d[k].table_lo = nullptr;
+    gb.vec_ok[k] = (g.width % 8 == 0) && (g.col0 % 8 == 0) && (g.ld_dst % 8 == 0) && (g.ld_table % 8 == 0) &&
+                   ((uintptr_t)g.dst % 16 == 0) && ((uintptr_t)g.table % 16 == 0) && ((uintptr_t)g.dst_lo % 16 == 0) &&
+                   ((uintptr_t)g.table_lo % 16 == 0);
+    if (g.n > n_max) n_max = g.n;
+  }
+  if (n_max == 0) return CUBE_OK;
+  int blocks = (n_max + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gather_rows_batch_kernel, dim3(blocks, n_desc), dim3(256), 0, (hipStream_t)stream, gb);
+  CUBE_CHECK_LAUNCH("cube_gather_rows_batch");
+  return CUBE_OK;
+}
+
+extern "C" int cube_tag_argmax(const float* x, int ld, int M, int col_a, int n_a, int32_t* out_a, int col_b, int n_b,
+                               int32_t* out_b, const void* table, const void* table_lo, int ld_table, int width, void* dst,
+                               void* dst_lo, int ld_dst, int col_dst, void* stream) {
+  CUBE_ENTRY();
+  if (M <= 0) return CUBE_OK;
+  if (!x || !out_a || n_a <= 0 || col_a < 0 || col_a + n_a > ld) CUBE_FAIL(CUBE_ERR_ARG, "cube_tag_argmax: bad first range");
+  if (out_b && (n_b <= 0 || col_b < 0 || col_b + n_b > ld)) CUBE_FAIL(CUBE_ERR_ARG, "cube_tag_argmax: bad second range");
+  if (dst && (!table || width <= 0 || width > ld_table || col_dst < 0 || col_dst + width > ld_dst || (dst_lo && !table_lo)))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_tag_argmax: bad embedding arguments");
+  hipLaunchKernelGGL(tag_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, M, col_a, n_a, out_a, col_b,
+                     n_b, out_b, (const uint16_t*)table, (const uint16_t*)(dst_lo ? table_lo : nullptr), ld_table, width,
+                     (uint16_t*)dst, (uint16_t*)dst_lo, ld_dst, col_dst);
+  CUBE_CHECK_LAUNCH("cube_tag_argmax");
+  return CUBE_OK;
+}
+
+extern "C" int cube_pack_tags(const int32_t* tags, int cap, int B, int T, int root, int32_t* out, void* stream) {
+  CUBE_ENTRY();
+  if (B <= 0 || T - root <= 0) return CUBE_OK;
+  if (!tags || !out || root < 0 || root > 1 || cap < B * T) CUBE_FAIL(CUBE_ERR_ARG, "cube_pack_tags: bad arguments");
+  const int n = B * (T - root);
+  hipLaunchKernelGGL(pack_tags_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tags, cap, B, T, root, out);
+  CUBE_CHECK_LAUNCH("cube_pack_tags");
+  return CUBE_OK;
+}
 
 extern "C" int cube_gather_rows(void* dst, void* dst_lo, int ld_dst, int col0, int width, const void* table,
                                 const void* table_lo, int ld_table, const int32_t* idx, const int32_t* dst_rows, int n,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 15  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 16  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -19,6 +19,16 @@ MAX_CONV_GROUPS = 32
 I8_SHIFT = 8    # CUBE_I8_SHIFT
 I8_ONE = 127 << I8_SHIFT  # CUBE_I8_ONE: int8x2 fixed point, x = (256*hi + lo) / I8_ONE (16 bits)
 LSTM8_HONE = I8_ONE  # hidden states of cube_bilstm_recurrent_i8: the same 16-bit planes
+
+
+class GatherDesc(ctypes.Structure):
+    """cube_gather_desc (include/cube_hip.h): one gather of cube_gather_rows_batch."""
+    _fields_ = [("dst", c_void_p), ("dst_lo", c_void_p), ("ld_dst", c_int), ("col0", c_int), ("width", c_int),
+                ("table", c_void_p), ("table_lo", c_void_p), ("ld_table", c_int), ("idx", c_void_p), ("dst_rows", c_void_p),
+                ("n", c_int)]
+
+
+GATHER_BATCH_MAX = 8
 
 
 class ConvGroups(ctypes.Structure):
@@ -93,6 +103,10 @@ SIGNATURES = {
     "cube_gemm_i8x2": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_void_p]),
     "cube_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),
+    "cube_gather_rows_batch": (c_int, [ctypes.POINTER(GatherDesc), c_int, c_void_p]),
+    "cube_tag_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cube_pack_tags": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,

@@ -424,6 +424,17 @@ class _HipNet:
                                               table.hi.data_ptr(), hip.ptr(table.lo) if lo else None, table.hi.shape[1],
                                               hip.ptr(idx), hip.ptr(rows), n, hip.stream_handle()), "cube_gather_rows")
 
+    def _gather_batch(self, items):
+        """several `_gather`s that do not write the same elements as ONE launch (cube_gather_rows_batch):
+        items = (dst Pair, ld, col0, width, table Pair, idx, rows, n)."""
+        descs = (hip.GatherDesc * len(items))()
+        for d, (dst, ld, col0, width, table, idx, rows, n) in zip(descs, items):
+            lo = dst.lo is not None and table.lo is not None
+            d.dst, d.dst_lo, d.ld_dst, d.col0, d.width = dst.hi.data_ptr(), (dst.lo.data_ptr() if lo else None), ld, col0, width
+            d.table, d.table_lo, d.ld_table = table.hi.data_ptr(), (table.lo.data_ptr() if lo else None), table.hi.shape[1]
+            d.idx, d.dst_rows, d.n = hip.ptr(idx), hip.ptr(rows), n
+        hip.check(hip.load().cube_gather_rows_batch(descs, len(items), hip.stream_handle()), "cube_gather_rows_batch")
+
     @staticmethod
     def _zero(pair, numel):
         pair.hi[:numel].zero_()
@@ -512,7 +523,11 @@ class _HipNet:
             # pad positions keep a zero char-level vector (unpack, utils.py:17-32); every other element
             # of XW0 is rewritten below for every row.  Without pads nothing needs clearing.
             self._zero(xw0, BT * lay.xw0_w)
-        gather(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT)
+        # the look-ups that depend on the batch's index arrays only, in one launch: word embeddings and the language
+        # embedding into XW0, the language embedding into the buffers the later layers read it from
+        self._gather_batch([(xw0, lay.xw0_w, 0, lay.word_emb, pk["word_emb"], bt["word_idx"], None, BT),
+                            (xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)] +
+                           [(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT) for dstb, ldb in lang_dsts])
         po = pk["char_pre_out"]
         hip.gemm(pool, pool_w, N, po["K"], po["W"], po["N"], po["bias"], hip.EPI_BF16_TANH, out0=xw0, ldo0=lay.xw0_w,
                  col0=lay.xw0_char, n_valid=ch, rowmap=bt["rowmap_word"], stream=st)
@@ -522,7 +537,6 @@ class _HipNet:
             hip.check(lib.cube_gather_rows(xw0.hi.data_ptr(), lo(xw0.lo), lay.xw0_w, lay.xw0_char, ch, src_hi,
                                            src_lo if xw0.lo is not None else None, lay.xw0_w, bt["dup_src"].data_ptr(),
                                            bt["dup_dst"].data_ptr(), n_dup, st), "cube_gather_rows")
-        gather(xw0, lay.xw0_w, lay.xw0_lang, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         # ---- external embeddings: sum_k MLP_k(e_k) / K, tanh   (parser.py:130-138, tagger.py:111-119)
         cat = pk.get("ext_h1cat") if bt.get("embs_whole") is not None else None
         n_ext, hn = len(pk["ext"]), pk["ext"][0]["h1"]["N"]
@@ -570,8 +584,6 @@ class _HipNet:
         else:
             xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
         resw = buf.get("resw", BT, wh, torch.float32)
-        for dstb, ldb in lang_dsts:
-            gather(dstb, ldb, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
         src, src_ld = xw0, lay.xw0_w
         for l, cv in enumerate(pk["word_convs"]):
             last = l == nword - 1
@@ -610,21 +622,26 @@ class _HipNet:
                  stream=st)
         tag_all = buf.get("tag_idx" + sfx, 3, cap, torch.int32)[:3 * cap].view(3, cap)  # upos, attrs, xpos
         tag_idx = tag_all[:, row_off:row_off + BT]
-        hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, tag_idx[0].data_ptr(), st), "cube_argmax_rows")
-        emb_idx = tag_idx[0]
+        ue = pk["upos_emb"]
         if "y_upos" in bt:  # gold tags given (training-time behaviour of forward, parser.py:185-188)
+            hip.check(lib.cube_argmax_rows(upos_log.data_ptr(), n_u, 0, n_u, BT, tag_idx[0].data_ptr(), st), "cube_argmax_rows")
             emb_idx = torch.zeros((B, T), dtype=torch.int32, device=self._device)
             emb_idx[:, root:] = bt["y_upos"]
             emb_idx = emb_idx.view(-1)
             bt["_gold_idx"] = emb_idx  # lives as long as the batch (the gather below is asynchronous)
-        self._gather(x, x_w, emb_col, 64, pk["upos_emb"], emb_idx, None, BT)
+            self._gather(x, x_w, emb_col, 64, ue, emb_idx, None, BT)
+        else:  # arg-max and the look-up of its embedding in one launch
+            lo_ok = x.lo is not None and ue.lo is not None
+            hip.check(lib.cube_tag_argmax(upos_log.data_ptr(), n_u, BT, 0, n_u, tag_idx[0].data_ptr(), 0, 0, None,
+                                          ue.hi.data_ptr(), ue.lo.data_ptr() if lo_ok else None, ue.hi.shape[1], 64,
+                                          x.hi.data_ptr(), x.lo.data_ptr() if lo_ok else None, x_w, emb_col, st), "cube_tag_argmax")
         q = pk["attrs_xpos"]
         n_ax = q["n_valid"]
         ax_log = buf.get("ax_log" + sfx, cap, n_ax, torch.float32)[row_off * n_ax:(row_off + BT) * n_ax].view(BT, n_ax)
         hip.gemm(x, x_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_F32, out0=ax_log, ldo0=n_ax, n_valid=n_ax,
                  stream=st)
-        hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, 0, n_a, BT, tag_idx[1].data_ptr(), st), "cube_argmax_rows")
-        hip.check(lib.cube_argmax_rows(ax_log.data_ptr(), n_ax, n_a, n_x, BT, tag_idx[2].data_ptr(), st), "cube_argmax_rows")
+        hip.check(lib.cube_tag_argmax(ax_log.data_ptr(), n_ax, BT, 0, n_a, tag_idx[1].data_ptr(), n_a, n_x, tag_idx[2].data_ptr(),
+                                      None, None, 0, 0, None, None, 0, 0, st), "cube_tag_argmax")
         return dict(tag_idx=tag_idx, tag_all=tag_all,
                     upos_logits=upos_log.view(B, T, n_u)[:, root:, :], ax_logits=ax_log.view(B, T, n_ax)[:, root:, :],
                     upos=tag_idx[0].view(B, T)[:, root:], attrs=tag_idx[1].view(B, T)[:, root:],
@@ -662,12 +679,11 @@ class Parser(_HipNet):
         xl0 = xl0_all if row_off == 0 else hip.Pair(xl0_all.hi[o:], None if xl0_all.lo is None else xl0_all.lo[o:])
         xm_w = p32(wh + lg)
         xm = buf.get("xm", BT, xm_w)
-        out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,
-                          ext_b_col=wh + lg, want_aux=want_aux)
-        # ---- morphology heads (parser.py:178-192); PM = [pre_morpho | lang | upos_emb]
+        # PM = [pre_morpho | lang | upos_emb], the input of the morphology heads (parser.py:178-192)
         pm_w = p32(wh + lg + 64)
         pm = buf.get("pm", BT, pm_w)
-        self._gather(pm, pm_w, wh, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        out = self._trunk(bt, xl0, xl0_w, [(xm, xm_w), (xl0, xl0_w), (pm, pm_w)], tap=xm, tap_w=xm_w, ext_b=xl0, ext_b_w=xl0_w,
+                          ext_b_col=wh + lg, want_aux=want_aux)
         q = pk["pre_morpho"]
         hip.gemm(xm, xm_w, BT, q["K"], q["W"], q["N"], q["bias"], hip.EPI_BF16_TANH, out0=pm, ldo0=pm_w,
                  n_valid=q["n_valid"], stream=st)
@@ -687,8 +703,8 @@ class Parser(_HipNet):
         # ---- BiLSTM (parser.py:194-202): per layer one projection GEMM + one persistent recurrent kernel
         xl_w = p32(2 * H + lg)
         xla, xlb = buf.get("xla", BT, xl_w), buf.get("xlb", BT, xl_w)
-        self._gather(xla, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
-        self._gather(xlb, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)
+        self._gather_batch([(xla, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT),
+                            (xlb, xl_w, 2 * H, lg, pk["lang_emb"], bt["lang_rows"], None, BT)])
         G2 = 2 * pk["lstm"][0]["G"]
         gx = buf.get("gx", BT, G2, torch.float32)
         src, src_ld = fr["xl0"], fr["xl0_w"]
@@ -773,9 +789,9 @@ class Parser(_HipNet):
                                              hip.stream_handle()), "cube_mst_decode")
         label_logits, labels = self._label_scores(bt, r["pp"], r["pp_w"], packed[0], labels_out=packed[1],
                                                   hl=r["hal"], hl_w=r["hal_w"], hl_col=r["hl_col"], slot=slot)
-        packed[2].copy_(r["upos"])
-        packed[3].copy_(r["xpos"])
-        packed[4].copy_(r["attrs"])
+        tag = r["tag_all"]   # (upos, attrs, xpos) of every position -> rows 2..4 = upos, xpos, attrs of the words
+        hip.check(hip.load().cube_pack_tags(tag.data_ptr(), tag.shape[1], B, bt["T"], self._root, packed[2].data_ptr(),
+                                            hip.stream_handle()), "cube_pack_tags")
         r.update(heads=packed[0], labels=labels, status=status, label_logits=label_logits, packed=packed, bt=bt)
         return r
 
@@ -841,6 +857,13 @@ class Parser(_HipNet):
     # and a group drains later at the end of a short run: 158k -> 152k in a 20-step region).  Below this length: no groups.
     PAIR_MIN_T = int(os.environ.get("CUBE_PAIR_MIN_T", "64"))
     N_SLOTS = 2 * PAIR + 1   # batches that may be in flight (submitted, not collected)
+
+    def in_flight_for(self, T):
+        """How many batches of sentence length T - 1 a caller should keep in flight: two groups and the batch being
+        submitted.  Without groups that is 3 -- measured in a 20-step region: 3 in flight 158k sentences/s, 5 or 7 in
+        flight 140..150k (the first stages run ahead and the last batches' later stages trail alone); in the steady
+        state the depth makes no difference."""
+        return 2 * (self.PAIR if T >= self.PAIR_MIN_T else 1) + 1
     N_GROUPS = N_SLOTS       # groups in flight: as many as batches, for when no two consecutive batches share a length
 
     def _init_pipeline(self):
@@ -1047,7 +1070,7 @@ class Parser(_HipNet):
             for item in it:
                 batch, start, h = feat(item)
                 pending.append((batch, start, self.submit(self._upload(h))))
-                if len(pending) == self.N_SLOTS:
+                if len(pending) >= self.in_flight_for(h["T"]):
                     retire()
             while pending:
                 retire()
@@ -1068,7 +1091,7 @@ class Parser(_HipNet):
                 if item is not None:
                     ahead.append(pool.submit(feat, item))
                 pending.append((batch, start, self.submit(self._upload(h))))
-                if len(pending) == self.N_SLOTS:
+                if len(pending) >= self.in_flight_for(h["T"]):
                     retire()
             while pending:
                 retire()

@@ -190,6 +190,43 @@ class TraceLib:
             self._need("gather dst" + nm, d, 2 * (dmax * ld_dst + col0 + width), 2)
         return 0
 
+    def cube_gather_rows_batch(self, descs, n_desc, stream):
+        assert 1 <= n_desc <= hip.GATHER_BATCH_MAX
+        written = []
+        for k in range(n_desc):
+            d = descs[k]
+            self.cube_gather_rows(d.dst, d.dst_lo, d.ld_dst, d.col0, d.width, d.table, d.table_lo, d.ld_table, d.idx, d.dst_rows,
+                                  d.n, stream)
+            written.append((d.dst, d.ld_dst, d.col0, d.col0 + d.width))
+        for i in range(n_desc):   # no ordering between the gathers of a launch: same buffer -> disjoint columns
+            for j in range(i):
+                a_, b_ = written[i], written[j]
+                assert a_[0] != b_[0] or a_[1] != b_[1] or a_[3] <= b_[2] or b_[3] <= a_[2], ("gathers overlap", i, j)
+        return 0
+
+    def cube_tag_argmax(self, x, ld, M, col_a, n_a, out_a, col_b, n_b, out_b, table, table_lo, ld_table, width, dst, dst_lo,
+                        ld_dst, col_dst, stream):
+        self.calls.append(("tag_argmax", M, n_a, n_b))
+        assert n_a > 0 and col_a >= 0 and col_a + n_a <= ld
+        self._need("tag_argmax x", x, 4 * ((M - 1) * ld + max(col_a + n_a, (col_b + n_b) if out_b else 0)), 4)
+        self._need("tag_argmax out_a", out_a, 4 * M, 4)
+        if out_b:
+            assert n_b > 0 and col_b + n_b <= ld
+            self._need("tag_argmax out_b", out_b, 4 * M, 4)
+        if dst:
+            assert table and width <= ld_table and col_dst + width <= ld_dst and (dst_lo is None or table_lo is not None)
+            for nm, t, d in (("", table, dst), ("_lo", table_lo if dst_lo else None, dst_lo)):
+                self._need("tag_argmax table" + nm, t, 2 * ((n_a - 1) * ld_table + width), 2)
+                self._need("tag_argmax dst" + nm, d, 2 * ((M - 1) * ld_dst + col_dst + width), 2)
+        return 0
+
+    def cube_pack_tags(self, tags, cap, B, T, root, out, stream):
+        self.calls.append(("pack_tags", B, T))
+        assert cap >= B * T and root in (0, 1)
+        self._need("pack_tags tags", tags, 4 * 3 * cap, 4)
+        self._need("pack_tags out", out, 4 * 3 * B * (T - root), 4)
+        return 0
+
     def cube_masked_mean_i8(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
                             stream):
         assert x_lo is not None and C % 16 == 0 and ld_x % 16 == 0
