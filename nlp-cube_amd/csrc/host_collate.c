@@ -202,7 +202,7 @@ static inline int word_set(PyObject* w, WordLayout* wl, int f, PyObject* v) {
 }
 
 #include <time.h>
-static double g_t[8];
+static double g_t[12]; /* 0..7: the stages of featurize_times; 8..11: sweeps A+B, C, D+E of the object pass */
 static long g_calls;
 static inline double now_s(void) {
   struct timespec ts;
@@ -229,6 +229,103 @@ static void* sc_alloc(int slot, size_t bytes, int zero) {
   }
   if (zero) memset(g_sc[slot], 0, bytes);
   return g_sc[slot];
+}
+
+/* ---- raw token -> word id, C side.  utils.py:284-289 looks every word up as word2int[word.lower()]; `featurize` remembers
+ * the answer per RAW token.  As a Python dict that was 140 ns per word on text that does not fit the caches (hash the str,
+ * probe the index, follow the entry, compare the key string: four dependent misses that nothing prefetches) -- 82 % of the
+ * object pass.  Here: open addressing over 64-byte slots keyed by the FNV-1a hash of the code points that the string sweep
+ * computes anyway; a slot holds the hash, the id and the code points themselves (up to 12 inline, longer words in an
+ * arena), so a hit is ONE cache line, verified exactly, and the line is prefetched while the strings are being read. */
+enum { WID_INLINE = 12 };
+typedef struct { uint64_t h; int32_t id; int32_t len; int32_t cp[WID_INLINE]; } WidSlot; /* len > WID_INLINE: cp[0] = arena offset */
+typedef struct {
+  WidSlot* slots;
+  size_t mask, used;
+  int32_t* arena;
+  size_t arena_len, arena_cap;
+} WidTable;
+enum { WID_MAX_ENTRIES = 1 << 19 }; /* then the table starts over (as the dict did at 2^20) */
+
+static void wid_free(WidTable* t) {
+  free(t->slots);
+  free(t->arena);
+  t->slots = NULL; t->arena = NULL; t->mask = t->used = t->arena_len = t->arena_cap = 0;
+}
+static int wid_init(WidTable* t, size_t n_slots) {
+  if (posix_memalign((void**)&t->slots, 64, n_slots * sizeof(WidSlot)) != 0) { t->slots = NULL; return -1; }
+  memset(t->slots, 0, n_slots * sizeof(WidSlot));
+  t->mask = n_slots - 1;
+  t->used = 0;
+  return 0;
+}
+static inline const int32_t* wid_cps(const WidTable* t, const WidSlot* s) {
+  return s->len > WID_INLINE ? t->arena + s->cp[0] : s->cp;
+}
+/* -> slot of the token, or the empty slot where it belongs */
+static inline WidSlot* wid_find(const WidTable* t, uint64_t h, const int32_t* cp, int32_t len) {
+  size_t i = (size_t)h & t->mask;
+  for (;;) {
+    WidSlot* s = &t->slots[i];
+    if (s->h == 0) return s;
+    if (s->h == h && s->len == len && memcmp(wid_cps(t, s), cp, sizeof(int32_t) * (size_t)len) == 0) return s;
+    i = (i + 1) & t->mask;
+  }
+}
+static int wid_insert(WidTable* t, uint64_t h, const int32_t* cp, int32_t len, int32_t id) {
+  if (t->used >= WID_MAX_ENTRIES) { /* start over, small */
+    wid_free(t);
+    if (wid_init(t, 1 << 16) != 0) return -1;
+  } else if (2 * (t->used + 1) > t->mask + 1) { /* grow: rehash into twice the slots */
+    WidTable big = *t;
+    if (wid_init(&big, 2 * (t->mask + 1)) != 0) return -1;
+    for (size_t i = 0; i <= t->mask; ++i) {
+      const WidSlot* s = &t->slots[i];
+      if (s->h == 0) continue;
+      size_t j = (size_t)s->h & big.mask;
+      while (big.slots[j].h != 0) j = (j + 1) & big.mask;
+      big.slots[j] = *s;
+      ++big.used;
+    }
+    free(t->slots);
+    *t = big;
+  }
+  WidSlot* s = wid_find(t, h, cp, len);
+  if (s->h != 0) { s->id = id; return 0; }
+  if (len > WID_INLINE) {
+    if (t->arena_len + (size_t)len > t->arena_cap) {
+      const size_t cap = 2 * (t->arena_len + (size_t)len) + 4096;
+      int32_t* a = (int32_t*)realloc(t->arena, cap * sizeof(int32_t));
+      if (!a) return -1;
+      t->arena = a;
+      t->arena_cap = cap;
+    }
+    if (t->arena_len + (size_t)len > 0x7fffffff) return -1;
+    memcpy(t->arena + t->arena_len, cp, sizeof(int32_t) * (size_t)len);
+    s->cp[0] = (int32_t)t->arena_len;
+    t->arena_len += (size_t)len;
+  } else {
+    memcpy(s->cp, cp, sizeof(int32_t) * (size_t)len);
+  }
+  s->h = h; s->id = id; s->len = len;
+  ++t->used;
+  return 0;
+}
+static void wid_capsule_free(PyObject* cap) {
+  WidTable* t = (WidTable*)PyCapsule_GetPointer(cap, "cube_wid_table");
+  if (t) { wid_free(t); free(t); }
+}
+/* wid_table_new() -> capsule: an empty token -> word id table for one vocabulary (one MorphoCollate) */
+static PyObject* wid_table_new(PyObject* self, PyObject* args) {
+  WidTable* t = (WidTable*)calloc(1, sizeof(WidTable));
+  if (!t || wid_init(t, 1 << 16) != 0) { free(t); return PyErr_NoMemory(); }
+  return PyCapsule_New(t, "cube_wid_table", wid_capsule_free);
+}
+/* wid_table_size(capsule) -> (entries, slots) */
+static PyObject* wid_table_size(PyObject* self, PyObject* cap) {
+  WidTable* t = (WidTable*)PyCapsule_GetPointer(cap, "cube_wid_table");
+  if (!t) return NULL;
+  return Py_BuildValue("(nn)", (Py_ssize_t)t->used, (Py_ssize_t)(t->mask + 1));
 }
 
 typedef struct {
@@ -286,13 +383,21 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
   int root, n_layers, n_case, n_threads, dedup = 0;
   Py_ssize_t L;
   unsigned long long groups_addr;
-  if (!PyArg_ParseTuple(args, "O!O!O!lO!iiinO!O!KiO|i", &PyList_Type, &sents, &PyDict_Type, &word2int, &PyDict_Type, &wid_cache,
+  if (!PyArg_ParseTuple(args, "O!O!OlO!iiinO!O!KiO|i", &PyList_Type, &sents, &PyDict_Type, &word2int, &wid_cache,
                         &unk, &PyArray_Type, &cp_tab, &root, &n_layers, &n_case, &L, &PyTuple_Type, &emb_out,
                         &PyTuple_Type, &emb_dims, &groups_addr, &n_threads, &ints_out, &dedup))
     return NULL;
   if (PyArray_TYPE(cp_tab) != NPY_INT32 || PyArray_NDIM(cp_tab) != 2 || PyArray_DIM(cp_tab, 0) != 2 ||
       !PyArray_IS_C_CONTIGUOUS(cp_tab)) {
     PyErr_SetString(PyExc_ValueError, "featurize: cp_tab must be a C-contiguous int32 [2, top] array");
+    return NULL;
+  }
+  WidTable* wtab = NULL; /* the C-side token cache (wid_table_new), or a dict as in round 2 */
+  if (PyCapsule_CheckExact(wid_cache)) {
+    wtab = (WidTable*)PyCapsule_GetPointer(wid_cache, "cube_wid_table");
+    if (!wtab) return NULL;
+  } else if (!PyDict_Check(wid_cache)) {
+    PyErr_SetString(PyExc_TypeError, "featurize: the token cache must be a dict or a wid_table_new() capsule");
     return NULL;
   }
   const Py_ssize_t K = PyTuple_GET_SIZE(emb_out);
@@ -426,6 +531,8 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         if (owned) wemb[n_wemb++] = el;
       }
     }
+    g_t[8] += now_s() - t_start;
+    double t_sw = now_s();
     /* sweep C: the strings: length, word id through the raw-token cache (lower-cased look-up, utils.py:284-289) */
     for (Py_ssize_t w = 0; !bad && w < N; ++w) {
       if (w + PF < N) {
@@ -473,8 +580,10 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         }
         if (bad) break;
         whash[w] = h;
+        if (wtab) __builtin_prefetch(&wtab->slots[(size_t)(h ? h : 1) & wtab->mask]); /* read by sweep C2 */
       }
       total_chars += len;
+      if (wtab) continue;
       PyObject* id = PyDict_GetItemWithError(wid_cache, t); /* borrowed */
       if (!id) {
         if (PyErr_Occurred()) { bad = 1; break; }
@@ -496,6 +605,27 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         wid[w] = (int32_t)v;
       }
     }
+    /* sweep C2: the word ids from the C-side cache (its slots were prefetched by sweep C); a token seen for the first
+     * time asks Python once: word2int[word.lower()], utils.py:284-289 */
+    if (wtab && !bad) {
+      cp_off[N] = (int32_t)total_chars;
+      for (Py_ssize_t w = 0; w < N; ++w) {
+        const uint64_t h = whash[w] ? whash[w] : 1; /* 0 marks an empty slot */
+        const int32_t* cp = cps + cp_off[w];
+        WidSlot* sl = wid_find(wtab, h, cp, wlen[w]);
+        if (sl->h != 0) { wid[w] = sl->id; continue; }
+        PyObject* lo = PyObject_CallMethodNoArgs(wstr[w], str_lower);
+        if (!lo) { bad = 1; break; }
+        PyObject* id = PyDict_GetItemWithError(word2int, lo);
+        Py_DECREF(lo);
+        if (!id && PyErr_Occurred()) { bad = 1; break; }
+        const long v = id ? PyLong_AsLong(id) : unk;
+        if (v == -1 && PyErr_Occurred()) { bad = 1; break; }
+        wid[w] = (int32_t)v;
+        if (wid_insert(wtab, h, cp, wlen[w], (int32_t)v) != 0) { PyErr_NoMemory(); bad = 1; break; }
+      }
+    }
+    g_t[9] += now_s() - t_sw; t_sw = now_s();
     if (!bad && K > 0) {
       int good = 1;
       /* sweep D: the emb lists -> their item arrays */
@@ -527,6 +657,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
         bad = 1;
       }
     }
+    g_t[10] += now_s() - t_sw;
     if (bad) goto fail;
   }
   cp_off[N] = (int32_t)total_chars;
@@ -811,9 +942,9 @@ static PyObject* write_back_flat(PyObject* self, PyObject* args) {
 /* timing() -> (calls, seconds in: sizes pass, object pass, index arrays, wait for the embedding copies, and of the index
  * arrays: code points, repeated words, length groups, character rows) since the last call */
 static PyObject* timing(PyObject* self, PyObject* args) {
-  PyObject* r = Py_BuildValue("(ldddddddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5], g_t[6], g_t[7]);
+  PyObject* r = Py_BuildValue("(lddddddddddd)", g_calls, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5], g_t[6], g_t[7], g_t[8], g_t[9], g_t[10]);
   g_calls = 0;
-  for (int i = 0; i < 8; ++i) g_t[i] = 0.0;
+  for (int i = 0; i < 12; ++i) g_t[i] = 0.0;
   return r;
 }
 
@@ -942,6 +1073,8 @@ static PyMethodDef methods[] = {
     {"fill_ragged", fill_ragged, METH_VARARGS, "ragged int64 values -> zero-padded int64 [N, width] rows"},
     {"featurize", featurize, METH_VARARGS, "Sentence objects -> packed index arrays + padded embedding rows of one batch"},
     {"write_back_flat", write_back_flat, METH_VARARGS, "result ids [n_words, 5] -> the words, in order"},
+    {"wid_table_new", wid_table_new, METH_NOARGS, "an empty C-side raw token -> word id table (capsule) for featurize"},
+    {"wid_table_size", wid_table_size, METH_O, "(entries, slots) of a wid_table_new() capsule"},
     {"timing", timing, METH_NOARGS, "accumulated seconds per stage of featurize since the last call"},
     {"geometry", geometry, METH_VARARGS, "words per sentence and longest word per sentence"},
     {"max_words", max_words, METH_VARARGS, "word count of the longest sentence"},

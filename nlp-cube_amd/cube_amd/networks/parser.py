@@ -245,10 +245,14 @@ class _HipNet:
         groups = (hip.ConvGroups * n)()
         enc = collate._encodings
         tab = collate.cp_table32()
+        # raw token -> word id: a C-side table of the helper module (one per collate = per vocabulary), else the dict
+        wid_cache = getattr(collate, "_wid_table", None)
+        if wid_cache is None:
+            wid_cache = collate._wid_table = hm.wid_table_new() if hasattr(hm, "wid_table_new") else collate._wid_cache
         try:
             for _ in range(4):
                 try:
-                    r = hm.featurize(batch, enc.word2int, collate._wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
+                    r = hm.featurize(batch, enc.word2int, wid_cache, enc.word2int["<UNK>"], tab, self._root, n,
                                      0 if l0 is None else l0["n_case"], L, tuple(b.numpy() for b in st["emb"]), dims,
                                      ctypes.addressof(groups), self._host_threads, st["ints"].numpy(),
                                      1 if self.dedup_words else 0)

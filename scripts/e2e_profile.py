@@ -80,4 +80,7 @@ c, t0_, t1_, t2_, t3_, *sub = host.load().timing()
 print("featurize (C), ms per call: sizes %.3f, objects %.3f, index arrays %.3f, embedding copies %.3f (%d calls)"
       % (t0_ / c * 1e3, t1_ / c * 1e3, t2_ / c * 1e3, t3_ / c * 1e3, c))
 print("  of the index arrays: code points %.3f, repeated words %.3f, length groups %.3f, character rows %.3f"
-      % tuple(x / c * 1e3 for x in sub))
+      % tuple(x / c * 1e3 for x in sub[:4]))
+if len(sub) >= 7:
+    print("  of the objects: Word objects (sweeps A, B) %.3f, strings + word ids (C) %.3f, embedding lists and arrays (D, E) %.3f"
+          % tuple(x / c * 1e3 for x in sub[4:7]))

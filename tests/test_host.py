@@ -425,6 +425,48 @@ def test_featurizer_errors_give_their_staging_set_back():
     assert p._featurize(good, col) is not None
 
 
+def test_c_token_table_equals_word2int_lookup():
+    """The C-side raw token -> word id table of `featurize` (host_collate.c, WidTable) against utils.py:284-289
+    (word2int[word.lower()], <UNK> otherwise): 40 000 distinct tokens so that the table grows several times, tokens
+    longer than the 12 inline code points (arena), mixed case (the id belongs to the RAW token), non-ASCII, and a second
+    pass that answers everything from the table."""
+    from cube_amd import host
+    from cube_amd.networks.parser import Parser
+    hm = host.load()
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    p.load_state_dict(sd)
+    col = MorphoCollate(enc)
+    rng = np.random.default_rng(17)
+    vocab = [w for w in enc.word2int if len(w) > 1][:200]
+    doc = synth.make_document(enc, [40] * 1000, seed=5, ext_word_emb=tuple(case["ext"]))
+    alphabet = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZäöüßÉ中"
+    for s_ in doc.sentences:
+        for w in s_.words:
+            r = rng.random()
+            if r < 0.1:
+                v = vocab[int(rng.integers(len(vocab)))]
+                w.word = v.upper() if rng.random() < 0.5 else v
+            else:
+                w.word = "".join(alphabet[int(k)] for k in rng.integers(0, len(alphabet), size=int(rng.integers(1, 30))))
+    unk = enc.word2int["<UNK>"]
+    for rep in range(2):
+        for a in range(0, 1000, 250):
+            sents = doc.sentences[a:a + 250]
+            fast = p._featurize(list(sents), col)
+            assert fast is not None
+            off = int(np.sum([(x + 3) // 4 * 4 for x in fast["sizes"][:5]]))
+            T = fast["T"]
+            got = fast["packed"][off:off + len(sents) * T].reshape(len(sents), T)[:, 1:]
+            exp = np.array([[enc.word2int.get(w.word.lower(), unk) for w in s_.words] for s_ in sents])
+            np.testing.assert_array_equal(got, exp)
+            p._staging_release(fast["staging"])
+    entries, slots = hm.wid_table_size(col._wid_table)
+    assert entries > 30000 and slots >= 2 * entries and slots > (1 << 16)
+    assert (exp != unk).any() and (exp == unk).any()
+
+
 def test_c_featurizer_very_long_words():
     """Words of thousands of characters: the featuriser's code-point buffer (sized for 8 characters per word) grows
     while the strings are being read, and the caller's index buffer is asked for again at its real size."""
