@@ -328,6 +328,192 @@ static PyObject* wid_table_size(PyObject* self, PyObject* cap) {
   return Py_BuildValue("(nn)", (Py_ssize_t)t->used, (Py_ssize_t)(t->mask + 1));
 }
 
+
+/* ---- a small persistent thread pool for the memory-bound sweeps of featurize.  The calling thread holds the GIL for the
+ * whole call and no Python code runs inside it, so the workers may READ Python objects (struct fields, list item arrays,
+ * str and ndarray payloads) without it; they never touch reference counts or call the C API.  Threads are created once
+ * (a pthread_create per call cost more than a sweep); a forked child starts without them. */
+enum { POOL_MAX = 16 };
+typedef void (*pool_fn)(void* ctx, int chunk, int n_chunks);
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t wake, done;
+  pthread_t th[POOL_MAX];
+  int n_threads;        /* workers alive */
+  unsigned long gen;    /* job generation */
+  pool_fn fn;
+  void* ctx;
+  int n_chunks, next, running;
+  int ready;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, NULL, NULL, 0, 0, 0, 0};
+
+static void* pool_worker(void* arg) {
+  unsigned long seen = 0;
+  pthread_mutex_lock(&g_pool.mu);
+  for (;;) {
+    while (g_pool.gen == seen) pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+    seen = g_pool.gen;
+    for (;;) {
+      const int c = g_pool.next;
+      if (c >= g_pool.n_chunks) break;
+      g_pool.next = c + 1;
+      ++g_pool.running;
+      pthread_mutex_unlock(&g_pool.mu);
+      g_pool.fn(g_pool.ctx, c, g_pool.n_chunks);
+      pthread_mutex_lock(&g_pool.mu);
+      --g_pool.running;
+    }
+    if (g_pool.running == 0) pthread_cond_signal(&g_pool.done);
+  }
+  return NULL;
+}
+static void pool_child_reset(void) { /* after fork(): the child has no workers, and the mutex state is the parent's */
+  pthread_mutex_init(&g_pool.mu, NULL);
+  pthread_cond_init(&g_pool.wake, NULL);
+  pthread_cond_init(&g_pool.done, NULL);
+  g_pool.n_threads = 0;
+  g_pool.gen = 0;
+  g_pool.n_chunks = g_pool.next = g_pool.running = 0;
+}
+/* fn(ctx, chunk, n_chunks) for every chunk, on up to `want` threads including the caller's; returns when all are done */
+static void pool_run(pool_fn fn, void* ctx, int n_chunks, int want) {
+  if (want > POOL_MAX) want = POOL_MAX;
+  if (want <= 1 || n_chunks <= 1) {
+    for (int c = 0; c < n_chunks; ++c) fn(ctx, c, n_chunks);
+    return;
+  }
+  pthread_mutex_lock(&g_pool.mu);
+  if (!g_pool.ready) {
+    pthread_atfork(NULL, NULL, pool_child_reset);
+    g_pool.ready = 1;
+  }
+  while (g_pool.n_threads < want - 1) {
+    if (pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, NULL) != 0) break;
+    pthread_detach(g_pool.th[g_pool.n_threads]);
+    ++g_pool.n_threads;
+  }
+  g_pool.fn = fn; g_pool.ctx = ctx; g_pool.n_chunks = n_chunks; g_pool.next = 0; g_pool.running = 0;
+  ++g_pool.gen;
+  pthread_cond_broadcast(&g_pool.wake);
+  for (;;) { /* the caller works too */
+    const int c = g_pool.next;
+    if (c >= g_pool.n_chunks) break;
+    g_pool.next = c + 1;
+    ++g_pool.running;
+    pthread_mutex_unlock(&g_pool.mu);
+    fn(ctx, c, n_chunks);
+    pthread_mutex_lock(&g_pool.mu);
+    --g_pool.running;
+  }
+  while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+  g_pool.n_chunks = 0; /* late wakers find nothing */
+  pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* The object pass of featurize on the pool, for documents in the plain format: every Word of one class with `word` and
+ * `emb` in __slots__, exact str, ready; emb a list / tuple of K contiguous float32 vectors.  Anything else sets `fallback`
+ * and featurize runs its serial sweeps (which also produce the error messages). */
+typedef struct {
+  Py_ssize_t N, K, B, L, top;
+  PyObject** wobj;
+  PyObject** wstr;
+  PyTypeObject* tp;
+  Py_ssize_t off_word, off_emb;
+  const Py_ssize_t* E;
+  int32_t *wlen, *wid, *cp_off, *cps;
+  const int32_t *sb, *si, *tab_char;
+  const float** esrc;
+  uint64_t* whash;
+  const WidTable* wtab;
+  Py_ssize_t chunk_maxlen[64];
+  volatile int fallback, missing;
+} ParCtx;
+
+static void par_sweep_objects(void* vctx, int chunk, int n_chunks) {
+  ParCtx* c = (ParCtx*)vctx;
+  const Py_ssize_t w0 = c->N * chunk / n_chunks, w1 = c->N * (chunk + 1) / n_chunks;
+  enum { PFD = 8 };
+  Py_ssize_t maxlen = 0;
+  /* Word -> str, emb list */
+  for (Py_ssize_t w = w0; w < w1; ++w) {
+    if (w + PFD < w1) { __builtin_prefetch(c->wobj[w + PFD]); __builtin_prefetch((char*)c->wobj[w + PFD] + 64); }
+    PyObject* o = c->wobj[w];
+    if (Py_TYPE(o) != c->tp) { c->fallback = 1; return; }
+    PyObject* t = *(PyObject**)((char*)o + c->off_word);
+    if (!t) { c->fallback = 1; return; }
+    c->wstr[w] = t;
+    __builtin_prefetch(t);
+    if (c->K > 0) {
+      PyObject* el = *(PyObject**)((char*)o + c->off_emb);
+      if (!el) { c->fallback = 1; return; }
+      __builtin_prefetch(el);
+    }
+  }
+  /* str -> length;  emb list -> arrays -> data pointers */
+  for (Py_ssize_t w = w0; w < w1; ++w) {
+    PyObject* t = c->wstr[w];
+    if (!PyUnicode_CheckExact(t) || !PyUnicode_IS_READY(t)) { c->fallback = 1; return; }
+    const Py_ssize_t len = PyUnicode_GET_LENGTH(t);
+    if (len > 0x3fffffff) { c->fallback = 1; return; }
+    c->wlen[w] = (int32_t)len;
+    if (len > maxlen) maxlen = len;
+    if (c->K > 0) {
+      PyObject* el = *(PyObject**)((char*)c->wobj[w] + c->off_emb);
+      if (!(PyList_CheckExact(el) || PyTuple_CheckExact(el)) || PySequence_Fast_GET_SIZE(el) != c->K) { c->fallback = 1; return; }
+      PyObject** items = PySequence_Fast_ITEMS(el);
+      __builtin_prefetch(items);
+    }
+  }
+  if (c->K > 0) {
+    for (Py_ssize_t w = w0; w < w1; ++w) {
+      PyObject** items = PySequence_Fast_ITEMS(*(PyObject**)((char*)c->wobj[w] + c->off_emb));
+      for (Py_ssize_t k = 0; k < c->K; ++k) __builtin_prefetch((char*)items[k] + 16);
+    }
+    for (Py_ssize_t w = w0; w < w1; ++w) {
+      PyObject** items = PySequence_Fast_ITEMS(*(PyObject**)((char*)c->wobj[w] + c->off_emb));
+      for (Py_ssize_t k = 0; k < c->K; ++k) {
+        PyObject* a = items[k];
+        if (!PyArray_Check(a) || PyArray_TYPE((PyArrayObject*)a) != NPY_FLOAT32 || PyArray_NDIM((PyArrayObject*)a) != 1 ||
+            PyArray_DIM((PyArrayObject*)a, 0) != c->E[k] || !PyArray_IS_C_CONTIGUOUS((PyArrayObject*)a)) {
+          c->fallback = 1;
+          return;
+        }
+        c->esrc[(size_t)k * c->B * c->L + (size_t)c->sb[w] * c->L + c->si[w]] = (const float*)PyArray_DATA((PyArrayObject*)a);
+      }
+    }
+  }
+  c->chunk_maxlen[chunk] = maxlen;
+}
+
+/* code points + their hash (cp_off is known), then the word ids of the tokens the table knows; -2 = ask Python */
+static void par_sweep_strings(void* vctx, int chunk, int n_chunks) {
+  ParCtx* c = (ParCtx*)vctx;
+  const Py_ssize_t w0 = c->N * chunk / n_chunks, w1 = c->N * (chunk + 1) / n_chunks;
+  enum { PFD = 8 };
+  for (Py_ssize_t w = w0; w < w1; ++w) {
+    if (w + PFD < w1) __builtin_prefetch(c->wstr[w + PFD]);
+    PyObject* t = c->wstr[w];
+    const Py_ssize_t len = c->wlen[w];
+    const int kind = PyUnicode_KIND(t);
+    const void* data = PyUnicode_DATA(t);
+    int32_t* out = c->cps + c->cp_off[w];
+    uint64_t h = 1469598103934665603ULL;
+    for (Py_ssize_t i = 0; i < len; ++i) {
+      const Py_UCS4 cp = PyUnicode_READ(kind, data, i);
+      out[i] = (int32_t)cp;
+      h = (h ^ (uint64_t)cp) * 1099511628211ULL;
+      if ((Py_ssize_t)cp >= c->top || c->tab_char[cp] < 0) c->missing = 1;
+    }
+    c->whash[w] = h;
+    __builtin_prefetch(&c->wtab->slots[(size_t)(h ? h : 1) & c->wtab->mask]);
+  }
+  for (Py_ssize_t w = w0; w < w1; ++w) {
+    const uint64_t h = c->whash[w] ? c->whash[w] : 1;
+    const WidSlot* sl = wid_find(c->wtab, h, c->cps + c->cp_off[w], c->wlen[w]);
+    c->wid[w] = sl->h != 0 ? sl->id : -2;
+  }
+}
+
 typedef struct {
   const float* const* src; /* [rows] source vector of a row, NULL = pad row */
   float* dst;
@@ -516,8 +702,72 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       }
       Py_DECREF(ws); /* the sentence keeps its list */
     }
+    /* The plain format on the thread pool (par_sweep_*): sweeps B .. E and the cached word ids, in chunks of words. */
+    int par_done = 0;
+    if (!bad && wtab && n_threads > 1 && N >= 1024) {
+      PyTypeObject* tp = Py_TYPE(wobj[0]);
+      if (wl.tp != tp) word_layout(tp, &wl);
+      if (wl.off[F_WORD] >= 0 && (K == 0 || wl.off[F_EMB] >= 0)) {
+        ParCtx pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.N = N; pc.K = K; pc.B = B; pc.L = L; pc.top = top;
+        pc.wobj = wobj; pc.wstr = wstr; pc.tp = tp; pc.off_word = wl.off[F_WORD]; pc.off_emb = K > 0 ? wl.off[F_EMB] : 0;
+        pc.E = E; pc.wlen = wlen; pc.wid = wid; pc.cp_off = cp_off; pc.sb = sb; pc.si = si; pc.tab_char = tab_char;
+        pc.esrc = esrc; pc.whash = whash; pc.wtab = wtab;
+        int nch = 4 * n_threads;
+        if (nch > 64) nch = 64;
+        if (nch > N / 256) nch = (int)(N / 256);
+        pool_run(par_sweep_objects, &pc, nch, n_threads);
+        if (!pc.fallback) {
+          total_chars = 0;
+          for (Py_ssize_t w = 0; w < N; ++w) { cp_off[w] = (int32_t)total_chars; total_chars += wlen[w]; }
+          cp_off[N] = (int32_t)total_chars;
+          for (int c = 0; c < nch; ++c) if (pc.chunk_maxlen[c] > W) W = pc.chunk_maxlen[c];
+          if (total_chars > 0x3fffffff) { PyErr_SetString(PyExc_ValueError, "featurize: too many characters in one batch"); bad = 1; }
+          if (!bad && (size_t)(total_chars + 1) * sizeof(int32_t) > g_sc_cap[14]) {
+            const size_t cap = 2 * (size_t)(total_chars + 1) * sizeof(int32_t);
+            int32_t* grown = (int32_t*)malloc(cap);
+            if (!grown) { PyErr_NoMemory(); bad = 1; }
+            else { free(g_sc[14]); g_sc[14] = grown; g_sc_cap[14] = cap; cps = grown; }
+          }
+          if (!bad) {
+            pc.cps = cps;
+            pool_run(par_sweep_strings, &pc, nch, n_threads);
+            if (pc.missing) { /* code points the table does not know yet go back to the caller, in order of appearance */
+              missing = PyList_New(0);
+              if (!missing) bad = 1;
+              for (Py_ssize_t c = 0; !bad && c < total_chars; ++c) {
+                const int32_t cp = cps[c];
+                if ((Py_ssize_t)cp >= top || tab_char[cp] < 0) {
+                  PyObject* v = PyLong_FromLong((long)cp);
+                  if (!v || PyList_Append(missing, v) != 0) { Py_XDECREF(v); bad = 1; break; }
+                  Py_DECREF(v);
+                }
+              }
+            }
+            for (Py_ssize_t w = 0; !bad && w < N; ++w) { /* tokens seen for the first time: word2int[word.lower()], once */
+              if (wid[w] != -2) continue;
+              const uint64_t h = whash[w] ? whash[w] : 1;
+              const int32_t* cp = cps + cp_off[w];
+              WidSlot* sl = wid_find(wtab, h, cp, wlen[w]); /* (an earlier word of this batch may have brought it in) */
+              if (sl->h != 0) { wid[w] = sl->id; continue; }
+              PyObject* lo = PyObject_CallMethodNoArgs(wstr[w], str_lower);
+              if (!lo) { bad = 1; break; }
+              PyObject* id = PyDict_GetItemWithError(word2int, lo);
+              Py_DECREF(lo);
+              if (!id && PyErr_Occurred()) { bad = 1; break; }
+              const long v = id ? PyLong_AsLong(id) : unk;
+              if (v == -1 && PyErr_Occurred()) { bad = 1; break; }
+              wid[w] = (int32_t)v;
+              if (wid_insert(wtab, h, cp, wlen[w], (int32_t)v) != 0) { PyErr_NoMemory(); bad = 1; break; }
+            }
+          }
+          par_done = 1;
+        }
+      }
+    }
     /* sweep B: the str and the emb list of every word (slot reads: borrowed; getattr results are kept) */
-    for (Py_ssize_t w = 0; !bad && w < N; ++w) {
+    for (Py_ssize_t w = 0; !bad && !par_done && w < N; ++w) {
       if (w + PF < N) { __builtin_prefetch(wobj[w + PF]); __builtin_prefetch((char*)wobj[w + PF] + 64); }
       int owned = 0;
       PyObject* t = word_peek(wobj[w], &wl, F_WORD, &owned);
@@ -534,7 +784,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     g_t[8] += now_s() - t_start;
     double t_sw = now_s();
     /* sweep C: the strings: length, word id through the raw-token cache (lower-cased look-up, utils.py:284-289) */
-    for (Py_ssize_t w = 0; !bad && w < N; ++w) {
+    for (Py_ssize_t w = 0; !bad && !par_done && w < N; ++w) {
       if (w + PF < N) {
         __builtin_prefetch(wstr[w + PF]);
         if (K > 0) __builtin_prefetch(wel[w + PF]);
@@ -607,7 +857,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     }
     /* sweep C2: the word ids from the C-side cache (its slots were prefetched by sweep C); a token seen for the first
      * time asks Python once: word2int[word.lower()], utils.py:284-289 */
-    if (wtab && !bad) {
+    if (wtab && !bad && !par_done) {
       cp_off[N] = (int32_t)total_chars;
       for (Py_ssize_t w = 0; w < N; ++w) {
         const uint64_t h = whash[w] ? whash[w] : 1; /* 0 marks an empty slot */
@@ -626,7 +876,7 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
       }
     }
     g_t[9] += now_s() - t_sw; t_sw = now_s();
-    if (!bad && K > 0) {
+    if (!bad && !par_done && K > 0) {
       int good = 1;
       /* sweep D: the emb lists -> their item arrays */
       for (Py_ssize_t w = 0; good && w < N; ++w) {

@@ -294,16 +294,21 @@ class _HipNet:
         ring = self.__dict__.setdefault("_staging", [])
         lock = self.__dict__.setdefault("_staging_lock", threading.Lock())
         with lock:
-            st = None
-            for cand in ring:
-                if not cand["busy"]:
-                    st = cand
-                    break
-            if st is None:
-                if len(ring) >= self._N_STAGING:
-                    raise hip.CubeHipError("more than %d featurised batches are waiting for their upload" % self._N_STAGING)
+            # a free set whose uploads have completed; else a new set while the ring may grow; else, in rotation, the free
+            # set whose uploads were enqueued longest ago (the first free one would be the set just released, whose event --
+            # the upload of the PREVIOUS batch -- is the one wait that is sure to block: 2.3 ms per batch, measured)
+            k0 = self.__dict__.get("_staging_next", 0)
+            order = [ring[(k0 + j) % len(ring)] for j in range(len(ring))]
+            free = [c for c in order if not c["busy"]]
+            st = next((c for c in free if c["event"] is None or c["event"].query()), None)
+            if st is None and len(ring) < self._N_STAGING:
                 st = dict(emb=[], ints=torch.empty(0, dtype=torch.int32), busy=False, event=None)
                 ring.append(st)
+            if st is None:
+                if not free:
+                    raise hip.CubeHipError("more than %d featurised batches are waiting for their upload" % self._N_STAGING)
+                st = free[0]
+            self._staging_next = (next(k for k, c in enumerate(ring) if c is st) + 1) % len(ring)
             st["busy"] = True
         if st["event"] is not None:
             st["event"].synchronize()

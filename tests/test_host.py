@@ -467,6 +467,55 @@ def test_c_token_table_equals_word2int_lookup():
     assert (exp != unk).any() and (exp == unk).any()
 
 
+def test_c_featurizer_thread_pool_equals_serial_sweeps():
+    """featurize's object pass on the thread pool (batches of >= 1024 words in the plain format) against its serial
+    sweeps (`_host_threads = 1`) and against collate_fn + `_prepare_host`: bit-identical arrays -- on a plain batch, with
+    code points the character table has not seen (they come back in the same order), with a 3000-character word, with new
+    tokens in every call, and with one Word of another class in the batch (the pool declines, the serial sweeps run)."""
+    from cube_amd.networks.parser import Parser
+    case = cases.TINY
+    cfg, enc, sd = cases.parser_model(case)
+    col_a, col_b = MorphoCollate(enc), MorphoCollate(enc)
+
+    def parser(threads):
+        q = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+        q.load_state_dict(sd)
+        q._host_threads = threads
+        q.dedup_words = True
+        return q
+    pa, pb = parser(8), parser(1)
+    doc = synth.make_document(enc, list(np.random.default_rng(3).integers(1, 40, size=300)), seed=9, ext_word_emb=tuple(case["ext"]))
+    assert sum(len(s_.words) for s_ in doc.sentences) >= 4096
+    doc.sentences[7].words[0].word = "\u00c5ngstr\u00f6m\U0001F600"   # code points outside the table
+    doc.sentences[150].words[-1].word = "Qx" * 1500
+    doc.sentences[299].words[0].word = "\u4e2d\u6587"
+
+    def same(sents):
+        fa, fb = pa._featurize(list(sents), col_a), pb._featurize(list(sents), col_b)
+        assert fa is not None and fb is not None
+        _assert_same_host_batch(fa, fb)
+        pa._staging_release(fa["staging"])
+        pb._staging_release(fb["staging"])
+        return fa
+    same(doc.sentences)
+    same(doc.sentences[100:260])
+    pa.dedup_words = pb.dedup_words = False
+    fa = same(doc.sentences)
+    slow = pb._prepare_host(col_b.collate_fn(list(doc.sentences), targets=False))
+    fa = pa._featurize(list(doc.sentences), col_a)
+    _assert_same_host_batch(fa, slow)
+    pa._staging_release(fa["staging"])
+
+    class Other:   # no __slots__: the getattr path, serial
+        pass
+    o = Other()
+    o.word, o.emb = doc.sentences[5].words[2].word, doc.sentences[5].words[2].emb
+    keep = doc.sentences[5].words[2]
+    doc.sentences[5].words[2] = o
+    same(doc.sentences)
+    doc.sentences[5].words[2] = keep
+
+
 def test_c_featurizer_very_long_words():
     """Words of thousands of characters: the featuriser's code-point buffer (sized for 8 characters per word) grows
     while the strings are being read, and the caller's index buffer is asked for again at its real size."""
