@@ -5,6 +5,7 @@ two rocprofv3 --pmc CSVs -> profiles/<name>_traffic.json.
 default; CfgI8 = the int8x2 tile)"""
 import csv
 import json
+import re
 import sys
 
 
@@ -12,13 +13,21 @@ TAG = sys.argv[4] if len(sys.argv) > 4 else "CfgBig"
 
 
 def mean_kb(path, counter):
-    vals = []
+    """mean over the launches of the bench batch: the first four distinct grids of the kernel in dispatch order are
+    char layers 1-4 of the timed batch (later legs of bench.py launch other shapes)"""
+    vals, grids = {}, []
     with open(path) as f:
         for r in csv.DictReader(f):
             n = r["Kernel_Name"]
             if "gemm_kernel<4" in n and TAG in n and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / max(len(vals), 1), len(vals)
+                if TAG == "CfgI8" and not re.search(r"CfgI8, true, false>", n):
+                    continue                    # the word convolution's instance of the tile
+                if r["Grid_Size"] not in grids and len(grids) < 4:
+                    grids.append(r["Grid_Size"])
+                if r["Grid_Size"] in grids:
+                    vals.setdefault(r["Grid_Size"], []).append(float(r["Counter_Value"]))
+    per_layer = [sum(v) / len(v) for v in vals.values()]          # one mean per layer, then the mean of the layers
+    return sum(per_layer) / max(len(per_layer), 1), sum(len(v) for v in vals.values())
 
 
 fetch, nf = mean_kb(sys.argv[1], "FETCH_SIZE")
