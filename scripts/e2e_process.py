@@ -43,6 +43,19 @@ def main():
         row = dict(batch_size=bs, merge=merge, sentences=m, seconds=dt, sentences_per_s=m / dt)
         print(json.dumps(row), flush=True)
         out["rows"].append(row)
+
+    def tensor_bytes(o):
+        if torch.is_tensor(o):
+            return o.numel() * o.element_size()
+        if isinstance(o, dict):
+            return sum(tensor_bytes(v) for v in o.values())
+        if isinstance(o, (list, tuple)):
+            return sum(tensor_bytes(v) for v in o)
+        return 0
+    # what process(max_tokens=32768) holds once it has seen its largest batches (grow-only workspace, 7 result slots, staging ring)
+    out["footprint"] = dict(device_bytes_peak=int(torch.cuda.max_memory_allocated()), device_bytes_reserved=int(torch.cuda.memory_reserved()),
+                            pinned_staging_bytes=int(tensor_bytes(p.__dict__.get("_staging", []))), staging_sets=len(p.__dict__.get("_staging", [])))
+    print(json.dumps(out["footprint"]), flush=True)
     # the same document with word frequencies as text has them (Zipf over a 20000-word pool): what Parser.dedup_words
     # (one character-CNN row per distinct (spelling, language) pair of a batch) is for
     zdoc = synth.make_document(enc, [32] * 1024, seed=9078, ext_word_emb=(300,))
