@@ -156,7 +156,7 @@ def cpu_baseline(cfg, enc, sd, docs, batch_size, budget_s=15.0, ext=(300,)):
                        % (done, len(sents[0].words), batch_size, dt))
 
 
-def end_to_end(p, enc, docs, n_target=8192):
+def end_to_end(p, enc, docs, n_target=32768):
     """Secondary number: `Parser.process(Document)` from Sentence objects to filled words — C
     featurisation, upload, the device pipeline, write-back — at batch_size 256 and at the reference's default 4
     (reference batches of equal padding geometry merged into device batches, results unchanged)."""

@@ -148,6 +148,15 @@ int cube_tag_argmax(const float* x, int ld, int M, int col_a, int n_a, int32_t* 
  * out int32 [3, B, T-root] = (upos, xpos, attrs) of the words: rows 2..4 of the result array (parser.py:428-431).    */
 int cube_pack_tags(const int32_t* tags, int cap, int B, int T, int root, int32_t* out, void* stream);
 
+/* The result arrays of a batch -> page-locked host memory (parser.py:432-447 reads them with .detach().cpu().numpy()):
+ * `bytes` (a multiple of 4) from device memory `src` to `dst_pinned`, written by a kernel's own stores on `stream` instead
+ * of a hipMemcpyAsync.  Why: a D->H copy that is enqueued early and waits for its batch's kernels sits in one of the
+ * runtime's in-order copy queues all that time, and the H->D uploads of the NEXT batches queue up behind it (measured:
+ * every second or third upload of Parser.process started only when the previous batch's decode had finished, DESIGN
+ * section 9.8).  dst_pinned must be device-visible pinned memory (hipHostMalloc / torch pin_memory); it is valid on the host
+ * once an event recorded on `stream` after the call has completed.                                                   */
+int cube_copy_to_pinned(const void* src, void* dst_pinned, size_t bytes, void* stream);
+
 /* WordGram tail: out[n, c] = bf16( sum_k weight[k] * sum_{p < len[n]} x_k[n*W + p, c] / max(len[n], 1) )
  * over the n_layers gated-layer outputs x_k (bf16 [N*W, ld_x], hi [+ lo] planes); x_hi / x_lo /
  * weight are HOST arrays of n_layers entries (x_lo may be NULL).  With weight = 1,..,1,2 this is

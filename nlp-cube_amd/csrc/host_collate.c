@@ -950,12 +950,20 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
      * there is none).  The character CNN's output for a word depends on nothing else (and on W, which is the batch's). */
     int32_t* rep = (int32_t*)sc_alloc(15, sizeof(int32_t) * (size_t)N, 0);
     if (!rep) { PyErr_NoMemory(); goto fail; }
+    size_t cap = 16;
+    while (cap < 2 * (size_t)N) cap <<= 1;
+    int32_t* slots = dedup ? (int32_t*)sc_alloc(16, sizeof(int32_t) * cap, 0) : NULL;
+    if (dedup && !slots) { PyErr_NoMemory(); goto fail; }
+    /* From here to the join of the embedding copies nothing touches a Python object or the interpreter: the index arrays
+     * are built from this call's own scratch copies (code points, lengths, ids) and the copies read the vectors' data
+     * through pointers taken above.  The GIL is released for that stretch, so that a caller that featurises on a thread
+     * of its own (Parser.feature_thread) overlaps it with the launches and the write-back of other batches.  What keeps
+     * the borrowed data alive meanwhile is the caller's contract: the sentences of the batch being featurised are not
+     * modified until the call returns (Parser.process never touches a batch before its featurisation is done). */
+    Py_ssize_t need_ints = -1;
+    PyThreadState* ts_saved = PyEval_SaveThread();
     Py_ssize_t n_dup = 0;
     if (dedup) {
-      size_t cap = 16;
-      while (cap < 2 * (size_t)N) cap <<= 1;
-      int32_t* slots = (int32_t*)sc_alloc(16, sizeof(int32_t) * cap, 0);
-      if (!slots) { PyErr_NoMemory(); goto fail; }
       memset(slots, 0xff, sizeof(int32_t) * cap);
       for (Py_ssize_t w = 0; w < N; ++w) {
         const int32_t* c = cps + cp_off[w];
@@ -1042,8 +1050,8 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     for (int p = 0; p < n_parts; ++p) offs[p + 1] = offs[p] + (sizes[p] + 3) / 4 * 4;
     const Py_ssize_t n_ints = offs[n_parts];
     if ((Py_ssize_t)(ibuf.len / 4) < n_ints) { /* the caller's index buffer is too small: tell it the size, it calls again */
-      result = PyLong_FromSsize_t(n_ints);
-      goto done;
+      need_ints = n_ints;
+      goto arrays_done;
     }
     int32_t* P = (int32_t*)ibuf.buf;
     memset(P, 0, (size_t)n_ints * 4);
@@ -1100,9 +1108,15 @@ static PyObject* featurize(PyObject* self, PyObject* args) {
     }
 
     g_t[2] += now_s() - t_start; t_start = now_s();
+  arrays_done:
     /* the embedding copies started above: what is left of them after the index arrays */
     for (int t = 0; t < n_started; ++t) pthread_join(th[t], NULL);
     n_started = 0;
+    PyEval_RestoreThread(ts_saved);
+    if (need_ints >= 0) {
+      result = PyLong_FromSsize_t(need_ints);
+      goto done;
+    }
 
     g_t[3] += now_s() - t_start; t_start = now_s();
     ++g_calls;

@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 16; }
+extern "C" int cube_abi_version(void) { return 17; }
 
 namespace {
 
@@ -473,6 +473,29 @@ extern "C" int cube_pack_tags(const int32_t* tags, int cap, int B, int T, int ro
   const int n = B * (T - root);
   hipLaunchKernelGGL(pack_tags_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tags, cap, B, T, root, out);
   CUBE_CHECK_LAUNCH("cube_pack_tags");
+  return CUBE_OK;
+}
+
+// results -> pinned host memory by a kernel's own stores (one dword per lane: 256-byte PCIe writes per wavefront)
+__global__ __launch_bounds__(256) void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+extern "C" int cube_copy_to_pinned(const void* src, void* dst_pinned, size_t bytes, void* stream) {
+  CUBE_ENTRY();
+  if (bytes == 0) return CUBE_OK;
+  if (!src || !dst_pinned || bytes % 4 != 0 || (uintptr_t)src % 4 != 0 || (uintptr_t)dst_pinned % 4 != 0 || bytes > ((size_t)1 << 30))
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_copy_to_pinned: needs 4-byte aligned pointers and a multiple of 4 bytes (at most 1 GiB)");
+  void* dptr = nullptr;
+  if (hipHostGetDevicePointer(&dptr, dst_pinned, 0) != hipSuccess || !dptr) {
+    (void)hipGetLastError();
+    CUBE_FAIL(CUBE_ERR_ARG, "cube_copy_to_pinned: the destination is not pinned (page-locked, device-visible) host memory");
+  }
+  const size_t n = bytes / 4;
+  hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)src, (uint32_t*)dptr, n);
+  CUBE_CHECK_LAUNCH("cube_copy_to_pinned");
   return CUBE_OK;
 }
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 16  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 17  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -107,6 +107,7 @@ SIGNATURES = {
     "cube_tag_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_pack_tags": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cube_copy_to_pinned": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,

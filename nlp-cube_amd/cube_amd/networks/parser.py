@@ -977,8 +977,12 @@ class Parser(_HipNet):
             if host is None or host.numel() < n + B:
                 host = torch.empty(n + B, dtype=torch.int32, pin_memory=True)
                 grp["host"] = host
-            host[:n].view(5, B, L).copy_(r["packed"], non_blocking=True)
-            host[n:n + B].copy_(r["status"], non_blocking=True)
+            # by a kernel's stores, not hipMemcpyAsync: a D->H copy waiting in the runtime's copy queue for this group's
+            # kernels holds up the uploads of the next batches (cube_hip.h, cube_copy_to_pinned)
+            lib = hip.load()
+            hip.check(lib.cube_copy_to_pinned(r["packed"].data_ptr(), host.data_ptr(), 4 * n, hip.stream_handle()), "cube_copy_to_pinned")
+            hip.check(lib.cube_copy_to_pinned(r["status"].data_ptr(), host.data_ptr() + 4 * n, 4 * B, hip.stream_handle()),
+                      "cube_copy_to_pinned")
             done = torch.cuda.Event()
             done.record(s3)
         grp.update(done=done, free=done, vbt=vbt, fr=None)
@@ -1075,10 +1079,14 @@ class Parser(_HipNet):
             if on_result is not None:
                 on_result(b0, s0, res)
 
+        def enqueue(h):
+            with self._upload_context():
+                return self.submit(self._upload(h))
+
         if not self.feature_thread:
             for item in it:
                 batch, start, h = feat(item)
-                pending.append((batch, start, self.submit(self._upload(h))))
+                pending.append((batch, start, enqueue(h)))
                 if len(pending) >= self.in_flight_for(h["T"]):
                     retire()
             while pending:
@@ -1099,7 +1107,7 @@ class Parser(_HipNet):
                 item = next(it, None)
                 if item is not None:
                     ahead.append(pool.submit(feat, item))
-                pending.append((batch, start, self.submit(self._upload(h))))
+                pending.append((batch, start, enqueue(h)))
                 if len(pending) >= self.in_flight_for(h["T"]):
                     retire()
             while pending:
@@ -1114,6 +1122,21 @@ class Parser(_HipNet):
                     pass
 
     feature_thread = os.environ.get("CUBE_FEATURE_THREAD", "0") == "1"
+    upload_stream = os.environ.get("CUBE_UPLOAD_STREAM", "null")
+
+    def _upload_context(self):
+        """The stream the H->D copies of `process` go to."""
+        import contextlib
+        if self.upload_stream == "null" or self._device.type != "cuda":
+            return contextlib.nullcontext()
+        if self._streams is None:
+            self._init_pipeline()
+        if self.upload_stream == "front":
+            return torch.cuda.stream(self._streams[0])
+        up = self.__dict__.get("_up_stream")
+        if up is None:
+            up = self._up_stream = torch.cuda.Stream(device=self._device)
+        return torch.cuda.stream(up)
 
     @hip.on_device
     def process_bucketed(self, doc, collate, max_tokens=8192, on_result=None):

@@ -227,6 +227,12 @@ class TraceLib:
         self._need("pack_tags out", out, 4 * 3 * B * (T - root), 4)
         return 0
 
+    def cube_copy_to_pinned(self, src, dst, nbytes, stream):
+        self.calls.append(("copy_to_pinned", nbytes))
+        assert nbytes % 4 == 0
+        self._need("copy_to_pinned src", src, nbytes, 4)
+        return 0
+
     def cube_masked_mean_i8(self, x_hi, x_lo, weight, n_layers, ld_x, length, N, W, C, out, out_lo, ld_out, word_rows,
                             stream):
         assert x_lo is not None and C % 16 == 0 and ld_x % 16 == 0
