@@ -68,6 +68,18 @@ struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR
 struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 4; };
 
 constexpr int MAX_TAPS = 5;
+#ifndef CUBE_EPI_PREFETCH
+#define CUBE_EPI_PREFETCH 1
+#endif
+// -DCUBE_GEMM_PROF (scripts/ab_build.py + scripts/gemm_phase_prof.py): wall-clock stamps (10 ns units) per workgroup of the
+// int8x2 character-CNN tile -- entry, prologue done, k-loop done, end -- read back with cube_gemm_prof()
+#ifdef CUBE_GEMM_PROF
+__device__ long long g_gemm_prof[4 * 4096];
+#define PROF_STAMP(name) const long long name = wall_clock64()
+#else
+#define PROF_STAMP(name)
+#endif
+constexpr bool EPI_PREFETCH = CUBE_EPI_PREFETCH != 0;  // (A/B switch of the int8x2 gate epilogue's first loads, scripts/ab_build.py)
 template <class C> constexpr int slab_rows() { return C::SR; }
 // LDS: [A slab x2 buffers][B tile x NB stages][one zero row][per tile row: bias-table offset, output
 // row, tap mask, slab row]; every operand buffer holds NP planes
@@ -158,6 +170,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   using acc_t = typename std::conditional<I8, i32x16, f32x16>::type;
   using frag_t = typename std::conditional<I8, i32x4, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PROF_STAMP(prof_t0);
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int NW = C::WM * C::WN;
   constexpr int TM = BM / C::WM / 32, TN = BN / C::WN / 32;  // 32x32 MFMA tiles per wave
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   }
 
   __syncthreads();  // drains the first DMAs (vmcnt(0)) and publishes the row tables
+  PROF_STAMP(prof_t1);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int lr = wr * (BM / C::WM) + i * 32 + l31;  // row inside the block tile
@@ -310,10 +324,37 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
   }
   // LDS-DMA instructions this wave issues per weight tile (what a counted wait leaves in flight)
   const bool b_full = B_EVEN || wid + NW * (PB - 1) < B_PIECES;
+  // int8x2 gate epilogue: what its first group of channels needs -- the weight scales and, for the lane's row in each of
+  // the wave's row tiles, the bias-table values -- is loaded under the MFMAs of the LAST k-step (pre_*), so that the
+  // epilogue starts computing at once and the loads of the other three groups arrive behind that math.  (Loaded at the top of
+  // the epilogue, every wave of the tile sat out one L2 round trip with the matrix cores idle: 143 -> 137 us per launch when
+  // the loads of both row tiles were at least issued together, -> ... with the first group ahead.)
+  float4 pre_ws[2] = {}, pre_b[I8 ? TM : 1][2] = {};
+  const float* bsrc_row[I8 ? TM : 1] = {};
+  if constexpr (I8) {
+    const int wcol0_ = n0 + wc * (BN / C::WN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int lr = wr * (BM / C::WM) + i * 32 + l31;
+      bsrc_row[i] = p.bias_tab ? p.bias_tab + (size_t)reinterpret_cast<const uint32_t*>(smem + ROWOFF_OFF)[lr] + wcol0_ : p.bias + wcol0_;
+    }
+  }
 
   int kc = 0, tap = 0, stg = 0;  // stg = weight stage of step s
   for (int s = 0; s < nk; ++s) {
     const bool last_tap = (tap == taps - 1);
+    if constexpr (I8 && EPI_PREFETCH) {
+      if (s == nk - 1) {
+        const int wcol0_ = n0 + wc * (BN / C::WN);
+        pre_ws[0] = *reinterpret_cast<const float4*>(p.w_scale + wcol0_ + 4 * lh);
+        pre_ws[1] = *reinterpret_cast<const float4*>(p.w_scale + wcol0_ + 32 + 4 * lh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          pre_b[i][0] = *reinterpret_cast<const float4*>(bsrc_row[i] + 4 * lh);
+          pre_b[i][1] = *reinterpret_cast<const float4*>(bsrc_row[i] + 32 + 4 * lh);
+        }
+      }
+    }
     // operands of later steps: one LDS-DMA piece after each MFMA group below (a piece costs the wave
     // 60-180 issue cycles; spread out, the queued MFMAs cover it, bunched at the top they do not)
     const bool pre = s + PD < nk;  // a weight tile to prefetch in this step
@@ -431,6 +472,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
 #undef ISSUE_A_PIECE
 #undef ISSUE_B_PIECE
 
+  PROF_STAMP(prof_t2);
   // ---- epilogue.  C/D map of 32x32x16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int wrow0 = m0 + wr * (BM / C::WM);
   const int wcol0 = n0 + wc * (BN / C::WN);
@@ -456,49 +498,71 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
       // i.e. one dword of each int8 plane.  The dwords go through wave-private LDS rows (32 bytes per
       // activation row and plane) so that the global stores are 16 bytes per lane.
       constexpr int SROW8 = 48;
-      unsigned char* stg = smem + wid * (2 * 32 * SROW8);
+      unsigned char* stg = smem + wid * (TM * 2 * 32 * SROW8);  // both row tiles of the wave are staged, then stored
       unsigned char* out8 = reinterpret_cast<unsigned char*>(p.out0);
       unsigned char* out8_lo = reinterpret_cast<unsigned char*>(p.out0_lo);
-      float4 ws_a[4], ws_b[4];
+      const int srow = lane >> 1, schunk = lane & 1;
+      const int chb = wcol0 / 2;  // first of the wave's 32 channels
+      // group 0 came in under the last k-step (pre_*); groups 1..3 are requested here, all at once, and used in order
+      float4 ws_a[4], ws_b[4], ba_all[TM][4], bb_all[TM][4];
+      if constexpr (!EPI_PREFETCH) {
+        pre_ws[0] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 4 * lh);
+        pre_ws[1] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 32 + 4 * lh);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int i = 0; i < TM; ++i) {
+          pre_b[i][0] = *reinterpret_cast<const float4*>(bsrc_row[i] + 4 * lh);
+          pre_b[i][1] = *reinterpret_cast<const float4*>(bsrc_row[i] + 32 + 4 * lh);
+        }
+      }
+      ws_a[0] = pre_ws[0];
+      ws_b[0] = pre_ws[1];
+#pragma unroll
+      for (int g = 1; g < 4; ++g) {
         ws_a[g] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 8 * g + 4 * lh);
         ws_b[g] = *reinterpret_cast<const float4*>(p.w_scale + wcol0 + 32 + 8 * g + 4 * lh);
       }
-      const int srow = lane >> 1, schunk = lane & 1;
-      const int chb = wcol0 / 2;  // first of the wave's 32 channels
+      int orow_i[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int lrow = wrow0 - m0 + i * 32 + l31;  // row inside the block tile
-        const int orow_l = orow_lds[lrow];           // this lane's output row (-1: none)
-        const float* bsrc = btab ? btab + (size_t)rowoff[lrow] + wcol0 : p.bias + wcol0;
-        float4 ba[4], bb[4];
+        orow_i[i] = orow_lds[wrow0 - m0 + i * 32 + l31];  // this lane's output row (-1: none)
+        ba_all[i][0] = pre_b[i][0];
+        bb_all[i][0] = pre_b[i][1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          ba[g] = *reinterpret_cast<const float4*>(bsrc + 8 * g + 4 * lh);
-          bb[g] = *reinterpret_cast<const float4*>(bsrc + 32 + 8 * g + 4 * lh);
+        for (int g = 1; g < 4; ++g) {
+          ba_all[i][g] = *reinterpret_cast<const float4*>(bsrc_row[i] + 8 * g + 4 * lh);
+          bb_all[i][g] = *reinterpret_cast<const float4*>(bsrc_row[i] + 32 + 8 * g + 4 * lh);
         }
+      }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float wa[4] = {ws_a[g].x, ws_a[g].y, ws_a[g].z, ws_a[g].w}, wb[4] = {ws_b[g].x, ws_b[g].y, ws_b[g].z, ws_b[g].w};
+      for (int g = 0; g < 4; ++g) {
+        const float wa[4] = {ws_a[g].x, ws_a[g].y, ws_a[g].z, ws_a[g].w}, wb[4] = {ws_b[g].x, ws_b[g].y, ws_b[g].z, ws_b[g].w};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int orow_l = orow_i[i];
+          const float4 *ba = ba_all[i], *bb = bb_all[i];
           const float xa[4] = {ba[g].x, ba[g].y, ba[g].z, ba[g].w}, xb[4] = {bb[g].x, bb[g].y, bb[g].z, bb[g].w};
-          uint32_t dh = 0, dl = 0;
           float gq[4];
+          uint32_t tq[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             const float ca = fmaf((float)acc[i][0][r], (float)(1 << CUBE_I8_SHIFT), (float)acc2[i][0][r]) * wa[e] + xa[e];
             const float cb = fmaf((float)acc[i][1][r], (float)(1 << CUBE_I8_SHIFT), (float)acc2[i][1][r]) * wb[e] + xb[e];
-            const float gv = tanhf_(ca) * sigmoidf_(cb);
+            const float gv = tanhf_(ca) * sigmoidf_(cb);  // in [-1, 1]: |q| <= CUBE_I8_ONE without a clamp
             gq[e] = gv;
-            int q = __float2int_rn(gv * (float)CUBE_I8_ONE);
-            q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-            const int h = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
-            dh |= (uint32_t)(h & 255) << (8 * e);
-            dl |= (uint32_t)((q - (h << CUBE_I8_SHIFT)) & 255) << (8 * e);
+            // q = round-to-nearest-even(gv * CUBE_I8_ONE) in ONE fma: 1.5 * 2^23 + 128 + gv * 32512 has unit spacing, so the low
+            // 16 bits of its bit pattern are t = q + 128 in two's complement; hi = t >> 8 is byte 1, lo = q - 256 * hi =
+            // (t & 255) - 128 is byte 0 with its top bit flipped (mul + round + convert + clamp + shifts: 11 operations before)
+            static_assert(CUBE_I8_SHIFT == 8, "the byte extraction below is written for 8 + 8 bits");
+            tq[e] = __float_as_uint(fmaf(gv, (float)CUBE_I8_ONE, 12582912.0f + 128.0f));
           }
-          *reinterpret_cast<uint32_t*>(stg + l31 * SROW8 + 8 * g + 4 * lh) = dh;
-          *reinterpret_cast<uint32_t*>(stg + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
+          // bytes 0 / 1 of the four values -> one dword each (v_perm_b32: selector 0-3 = bytes of the second operand, 4-7 = first)
+          const uint32_t p01 = __builtin_amdgcn_perm(tq[1], tq[0], 0x05010400u), p23 = __builtin_amdgcn_perm(tq[3], tq[2], 0x05010400u);
+          const uint32_t dl = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+          const uint32_t dh = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+          unsigned char* stg_i = stg + i * (2 * 32 * SROW8);
+          *reinterpret_cast<uint32_t*>(stg_i + l31 * SROW8 + 8 * g + 4 * lh) = dh;
+          *reinterpret_cast<uint32_t*>(stg_i + 32 * SROW8 + l31 * SROW8 + 8 * g + 4 * lh) = dl;
           if constexpr (RES8) {  // word-level stack: fp32 residual stream (res_mode 0: = g, 1: += g) and the x + res side outputs
             const int c0 = chb + 8 * g + 4 * lh;  // four consecutive channels of this lane's row
             if (orow_l >= 0 && c0 < p.n_valid) {
@@ -527,20 +591,28 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
             }
           }
         }
-        if (out8) {  // (uniform) int8x2 planes of the gate values for the next layer
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          const int cbase = wcol0 / 2 + schunk * 16;
+      }
+      if (out8) {  // (uniform) int8x2 planes of the gate values for the next layer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cbase = wcol0 / 2 + schunk * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned char* stg_i = stg + i * (2 * 32 * SROW8);
           const int row = orow_lds[wrow0 - m0 + i * 32 + srow];  // -1 = none
           if (row >= 0 && cbase < p.n_valid) {
             const size_t o = (size_t)row * p.ldo0 + p.col0 + cbase;  // bytes
-            *reinterpret_cast<uint4*>(out8 + o) = *reinterpret_cast<const uint4*>(stg + srow * SROW8 + schunk * 16);
-            *reinterpret_cast<uint4*>(out8_lo + o) = *reinterpret_cast<const uint4*>(stg + 32 * SROW8 + srow * SROW8 + schunk * 16);
+            *reinterpret_cast<uint4*>(out8 + o) = *reinterpret_cast<const uint4*>(stg_i + srow * SROW8 + schunk * 16);
+            *reinterpret_cast<uint4*>(out8_lo + o) = *reinterpret_cast<const uint4*>(stg_i + 32 * SROW8 + srow * SROW8 + schunk * 16);
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
         }
       }
+#ifdef CUBE_GEMM_PROF
+      if (!RES8 && tid == 0 && blockIdx.x < 4096) {
+        long long* q_ = g_gemm_prof + 4 * blockIdx.x;
+        q_[0] = prof_t0; q_[1] = prof_t1; q_[2] = prof_t2; q_[3] = wall_clock64();
+      }
+#endif
       return;
     } else if (p.vec_out) {
       // no residual stream (character CNN): transpose each 32x32 gate tile through wave-private LDS
@@ -873,3 +945,9 @@ extern "C" int cube_gemm_i8x2(const cube_gemm_args* a, const float* w_scale, voi
   if (!w_scale) CUBE_FAIL(CUBE_ERR_ARG, "cube_gemm_i8x2: null w_scale");
   return gemm_entry(a, w_scale, stream);
 }
+
+#ifdef CUBE_GEMM_PROF
+extern "C" int cube_gemm_prof(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 4 * 4096) == hipSuccess ? 0 : 1;
+}
+#endif
