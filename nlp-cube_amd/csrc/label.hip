@@ -174,9 +174,15 @@ extern "C" int cube_label_score(const void* hl, const void* hl_lo, int ld_hl, in
     CUBE_FAIL(CUBE_ERR_ALIGN, "cube_label_score: operands must be 16-byte aligned");
   const int M = B * L;
   const int row_blocks = (M + 127) / 128;
-  // enough label groups to give every SIMD of the chip a wave
-  // (two waves per SIMD -- twice the groups -- measured 10 % slower: the x1 / x2 set-up is per workgroup)
-  int groups = (1024 + row_blocks * 4 - 1) / (row_blocks * 4);
+  // Label groups: enough for a wave on every second SIMD of the chip, no more.  Alone the kernel is fastest with a wave on
+  // EVERY SIMD (1024 waves: 122 us; two waves per SIMD 10 % slower: the x1 / x2 set-up is per workgroup), but it runs beside
+  // the character-CNN GEMMs of the next batches, whose tiles need a whole CU each (159.8 KB of LDS, 464 of 512 registers per
+  // SIMD): spread over all 256 CUs at one wave per SIMD it kept GEMM tiles off the whole chip while using a quarter of it.
+  // A/B in the pipelined bench on one box: 1024 waves 170.8k sentences/s, 2048 172.0k, 512 175.7k, 256 175.7k.
+#ifndef CUBE_LABEL_WAVES
+#define CUBE_LABEL_WAVES 512
+#endif
+  int groups = (CUBE_LABEL_WAVES + row_blocks * 4 - 1) / (row_blocks * 4);
   if (groups < 1) groups = 1;
   if (groups > n_labels) groups = n_labels;
   const int per = (n_labels + groups - 1) / groups;
