@@ -953,6 +953,28 @@ def test_merged_reference_batches_do_not_change_results(dev):
     assert str(tdocs[0]) == str(tdocs[1])
 
 
+@pytest.mark.parametrize("feature_thread,upload_stream", [(True, "null"), (True, "own"), (False, "own"), (False, "front")])
+def test_process_host_options_do_not_change_results(dev, feature_thread, upload_stream):
+    """`Parser.feature_thread` (featurisation one batch ahead on a thread of its own: the C pass releases the GIL while
+    it builds the index arrays) and `Parser.upload_stream` (H->D copies on the caller's stream / a stream of their own /
+    the front stage's stream) only move host work and copies: the filled document is identical to the default's."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.TINY
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    rng = np.random.default_rng(12)
+    lens = rng.integers(1, 9, size=1500)   # enough words per merged device batch for the featuriser's thread pool
+    docs = [synth.make_document(enc, lens, seed=79, ext_word_emb=case["ext"], max_word_len=6) for _ in range(2)]
+    col = MorphoCollate(enc)
+    p.process(docs[0], col, batch_size=32)
+    p.feature_thread, p.upload_stream = feature_thread, upload_stream   # instance attributes shadow the class defaults
+    try:
+        p.process(docs[1], col, batch_size=32)
+    finally:
+        del p.feature_thread, p.upload_stream
+    assert str(docs[0]) == str(docs[1])
+
+
 def test_pipelined_submit_equals_serial_decode(dev):
     """`submit` / `collect` (three stage streams, N_SLOTS batches in flight, slot buffers reused) give
     bit-identical result arrays to the single-stream `decode_batch_prepared`, for batches of different
