@@ -1157,8 +1157,11 @@ class Parser(_HipNet):
     @hip.on_device
     def process(self, doc, collate, batch_size=4, num_workers=4, merge=True, max_tokens=32768, on_result=None):
         """reference: parser.py:404-448 — in-order batches of `batch_size` sentences; fills
-        head/label/upos/xpos/attrs of every word of `doc` and returns it.  Batches are pipelined
-        two deep (featurisation and write-back of neighbours overlap the GPU).
+        head/label/upos/xpos/attrs of every word of `doc` and returns it.  `in_flight_for(T)` device batches are
+        in flight (3 for short sentences, 7 when later stages run per group of batches): featurisation and
+        write-back of neighbours overlap the GPU.  `max_tokens` (default 32768 padded tokens per device batch) sets
+        the footprint: 3.6 GB of device memory at the peak and ~100 MB of pinned staging at the default
+        (INTEGRATION.md, section 3); 8192 takes a quarter of both at -5 % sentences/s.
         merge (no counterpart in the reference, results unchanged): reference batches with the same
         padding geometry (longest sentence, longest word) run together as one device batch of up to
         `max_tokens` padded tokens — every sentence still sees exactly the padding of its own
