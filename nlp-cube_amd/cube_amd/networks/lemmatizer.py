@@ -183,7 +183,9 @@ class Lemmatizer:
         M = B * S
         parts = [x_char.reshape(-1), X["x_case"].cpu().numpy().reshape(-1), np.repeat(X["x_upos"].cpu().numpy(), S),
                  np.repeat(X["x_lang"].cpu().numpy(), S)]
-        ints = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(dev, non_blocking=True)
+        # from pinned memory: a pageable source would make the copy wait, with the host, for the previous batch's kernels
+        ints = torch.from_numpy(np.concatenate(parts).astype(np.int32))
+        ints = (ints.pin_memory() if dev.type == "cuda" else ints).to(dev, non_blocking=True)
         char_i, case_i, upos_i, lang_i = (ints[k * M:(k + 1) * M] for k in range(4))
         self._live = [ints]  # per-batch device inputs: referenced until the next batch replaces them
         xe0 = buf.get("xe0", M, lay.xe0_w)
@@ -212,9 +214,11 @@ class Lemmatizer:
         return dict(B=B, S=S, enc=enc, e_enc=e_enc, ld_e=ae["N"], _ints=ints)
 
     @hip.on_device
-    def _decode(self, ed, max_steps=None, keep_logits=False):
+    def _decode(self, ed, max_steps=None, keep_logits=False, defer=False):
         """Greedy decoding (lemmatizer.py:126-169).  -> (out_char i32 [B, n], out_case i32 [B, n], n, logits)
-        with n = the number of steps the reference would have run."""
+        with n = the number of steps the reference would have run.  defer: everything is enqueued, the arg-max arrays are
+        written to pinned memory by a kernel (cube_copy_to_pinned) and a handle for `_decode_finish` is returned instead, so
+        that the caller can featurise and enqueue the NEXT batch before it waits for this one."""
         lib, pk, lay, buf, dev, st = hip.load(), self._pk, self._lay, self._buf, self._device, hip.stream_handle()
         B, S = ed["B"], ed["S"]
         limit = S * 20 if max_steps is None else max_steps
@@ -279,7 +283,31 @@ class Lemmatizer:
             if s > 0 and s % self.CHECK_EVERY == 0 and int(flags[B].item()) == B:
                 break
             lstm()
+        if defer:
+            n_int = out.numel()
+            ring = self.__dict__.setdefault("_pinned_ring", [])
+            slot = self.__dict__.get("_pinned_next", 0)
+            self._pinned_next = (slot + 1) % 3     # at most two handles are outstanding at any time (process loops below)
+            while len(ring) <= slot:
+                ring.append(torch.empty(0, dtype=torch.int32))
+            if ring[slot].numel() < n_int:
+                ring[slot] = torch.empty(n_int, dtype=torch.int32, pin_memory=True)
+            hip.check(lib.cube_copy_to_pinned(out.data_ptr(), ring[slot].data_ptr(), 4 * n_int, st), "cube_copy_to_pinned")
+            ev = torch.cuda.Event()
+            ev.record()
+            return dict(host=ring[slot], shape=tuple(out.shape), steps=steps, event=ev, out=out, logits=logits)
         res = out[:, :, :max(steps, 1)].cpu().numpy()
+        return self._trim(res, steps, logits)
+
+    def _decode_finish(self, h):
+        """Wait for a deferred `_decode` and trim its arrays as the synchronous form does."""
+        h["event"].synchronize()
+        steps = h["steps"]
+        res = h["host"][:int(np.prod(h["shape"]))].numpy().reshape(h["shape"])[:, :, :max(steps, 1)].copy()
+        h["out"] = None
+        return self._trim(res, steps, h["logits"])
+
+    def _trim(self, res, steps, logits):
         oc, ok = res[0][:, :steps], res[1][:, :steps]
         # the reference stops right after the step at which the last word emitted EOL (lemmatizer.py:139)
         n = steps
@@ -307,6 +335,26 @@ class Lemmatizer:
         self._require_gpu()
         oc, ok, _, _ = self._decode(self._encode(X), max_steps=self.max_steps)
         return oc, ok
+
+    @hip.on_device
+    def _decode_batches(self, batches, collate):
+        """batches: iterable of lists of items for `collate`.  Yields (index, lemma strings) per batch, in order, with the
+        host work of neighbouring batches (collate of the next, strings of the previous) under the device's decode."""
+        def finish(k, h):
+            oc, ok, _, _ = self._decode_finish(h)
+            return k, self._strings(oc, ok)
+
+        pending = None
+        for k, items in enumerate(batches):
+            batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
+            batch.pop("y_char", None)
+            batch.pop("y_case", None)
+            h = self._decode(self._encode(batch), max_steps=self.max_steps, defer=True)
+            if pending is not None:
+                yield finish(*pending)
+            pending = (k, h)
+        if pending is not None:
+            yield finish(*pending)
 
     def _strings(self, oc, ok):
         """arg-max ids -> lemma strings (lemmatizer.py:210-224): characters up to the first EOL, the case
@@ -353,28 +401,32 @@ class Lemmatizer:
         depend on batch composition.  Words longer than 25 characters keep their lemma (the
         reference's dataset skips them, utils.py:109-110, and then mis-assigns, lemmatizer.py:225-229)."""
         self._require_gpu()
-        keys = {}
+        keys, order, targets, widx = {}, [], [], []   # key -> index, keys by index, the words to fill, their key's index
         for sent in doc.sentences:
+            lang = sent.lang_id
             for w in sent.words:
-                if len(w.word) <= 25:
-                    keys.setdefault((w.word, w.upos, sent.lang_id), None)
-        by_len = {}
-        for k in keys:
-            by_len.setdefault(len(k[0]), []).append(k)
-        for n in sorted(by_len):
-            group = by_len[n]
-            for s in range(0, len(group), max_words):
-                part = group[s:s + max_words]
-                items = [{"word": k[0], "upos": k[1], "lang_id": k[2], "target": ""} for k in part]
-                batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
-                batch.pop("y_char", None)
-                batch.pop("y_case", None)
-                for k, lemma in zip(part, self._strings(*self.decode_batch(batch))):
-                    keys[k] = lemma
-        for sent in doc.sentences:
-            for w in sent.words:
-                if len(w.word) <= 25:
-                    w.lemma = keys[(w.word, w.upos, sent.lang_id)]
+                word = w.word
+                if len(word) <= 25:
+                    k = (word, w.upos, lang)
+                    i = keys.get(k)
+                    if i is None:
+                        i = keys[k] = len(order)
+                        order.append(k)
+                    targets.append(w)
+                    widx.append(i)
+        lens = np.fromiter((len(k[0]) for k in order), dtype=np.int64, count=len(order))
+        perm = np.argsort(lens, kind="stable")
+        parts = []   # lists of key indices: equal word length, at most max_words each
+        cuts = np.flatnonzero(np.diff(lens[perm])) + 1
+        for seg in np.split(perm, cuts):
+            parts += [seg[s:s + max_words].tolist() for s in range(0, len(seg), max_words)]
+        items = ([{"word": order[i][0], "upos": order[i][1], "lang_id": order[i][2], "target": ""} for i in part] for part in parts)
+        lemma_of = [None] * len(order)
+        for b, lemmas in self._decode_batches(items, collate):
+            for i, lemma in zip(parts[b], lemmas):
+                lemma_of[i] = lemma
+        for w, i in zip(targets, widx):
+            w.lemma = lemma_of[i]
         return doc
 
     @hip.on_device
@@ -396,12 +448,8 @@ class Lemmatizer:
         else:
             device_batches = [list(range(a, min(a + batch_size, n))) for a in starts]
         all_lemmas = [None] * n
-        for ids in device_batches:
-            items = [dataset[i] for i in ids]
-            batch = collate.collate_fn(items, targets=False) if isinstance(collate, Word2TargetCollate) else collate.collate_fn(items)
-            batch.pop("y_char", None)
-            batch.pop("y_case", None)
-            for i, lemma in zip(ids, self._strings(*self.decode_batch(batch))):
+        for b, lemmas in self._decode_batches(([dataset[i] for i in ids] for ids in device_batches), collate):
+            for i, lemma in zip(device_batches[b], lemmas):
                 all_lemmas[i] = lemma
         i = 0
         for sent in doc.sentences:
