@@ -177,9 +177,12 @@ int cube_masked_mean(const void* const* x_hi, const void* const* x_lo, const flo
  * and the output is tanh(.)*sigmoid(.) as bf16 hi (+ lo) rows [row, 0..half).  Rows follow `groups`
  * (cube_conv_groups of layer 0: cc is indexed by INPUT row, the output rows of the groups must be
  * contiguous from 0).  HBM/L2-bound (taps + 1 table rows per position) instead of an MFMA GEMM
- * over K = taps * (char_emb + case_emb).                                                         */
+ * over K = taps * (char_emb + case_emb).  zero_code: a (character, case) combination whose rows of T are
+ * all zero in every tap -- the padding character, whose embedding rows are zero (modules.py:430-431,
+ * padding_idx = 0) -- or -1: its rows are not read (the positions past a word's end, which layer 0 computes
+ * for the layers above it, are most of the look-ups).                                              */
 int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                           const cube_conv_groups* groups, int taps, int half, int n_combo,
+                           const cube_conv_groups* groups, int taps, int half, int n_combo, int zero_code,
                            void* out, void* out_lo, int ld_out, void* stream);
 
 /* ---- int8x2 fixed point for the gated convolutions whose inputs are gate outputs (|x| < 1) --------
@@ -204,7 +207,7 @@ int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc,
 #define CUBE_I8_ONE 32512 /* 127 << CUBE_I8_SHIFT */
 int cube_gemm_i8x2(const cube_gemm_args* args, const float* w_scale, void* stream);
 int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                              const cube_conv_groups* groups, int taps, int half, int n_combo,
+                              const cube_conv_groups* groups, int taps, int half, int n_combo, int zero_code,
                               void* out, void* out_lo, int ld_out, void* stream);
 int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const float* weight, int n_layers,
                         int ld_x, const int32_t* len, int N, int W, int C,

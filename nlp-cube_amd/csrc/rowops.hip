@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 17; }
+extern "C" int cube_abi_version(void) { return 18; }
 
 namespace {
 
@@ -233,25 +233,28 @@ __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int l
 }
 
 // ---- first gated character layer as table look-ups (see cube_char_conv0_lookup in the header)
+// first output row past each sequence group, computed by the host: the kernel's row -> group search is then compares only (a
+// loop with an integer division per group and thread was most of the kernel's time: 78.9 -> .. us per launch)
+struct Conv0Ends { int end[CUBE_MAX_CONV_GROUPS]; };
 template <bool I8>
 __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restrict__ T, const float* __restrict__ btab,
                                                            const int32_t* __restrict__ cc, const int32_t* __restrict__ lang_word,
-                                                           const cube_conv_groups cg, int taps, int half, int n_combo,
+                                                           const cube_conv_groups cg, const Conv0Ends ce, int taps, int half, int n_combo,
                                                            uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, int ld_out,
-                                                           int tpr, int rpb, int total_rows) {
+                                                           int tpr, int rpb, int total_rows, int zero_code) {
   const int r_local = threadIdx.x / tpr;
   const int row = blockIdx.x * rpb + r_local;
   if (r_local >= rpb || row >= total_rows) return;
   const int c4 = (threadIdx.x - r_local * tpr) * 4;
   int g = 0;
-  for (; g < cg.n - 1; ++g)
-    if (row < cg.row0_out[g] + cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g]) break;
+#pragma unroll
+  for (int i = 0; i < CUBE_MAX_CONV_GROUPS - 1; ++i) g += (i < cg.n - 1 && row >= ce.end[i]) ? 1 : 0;  // ends are non-decreasing
   const int seq_in = cg.seq_in[g], seq_out = cg.seq_out[g];
   const int rel = row - cg.row0_out[g];
   const int j = rel / seq_out, pos = rel - j * seq_out;
   const int in0 = cg.row0_in[g] + j * seq_in + pos - (taps >> 1);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-  unsigned mask = 0;
+  unsigned mask = 0, ldm = 0;  // taps inside the sequence (selects the bias row) / taps whose table row is read
   const size_t F = 2 * (size_t)half;
   // all character codes first, then all table rows (ten 16-byte loads in flight), then the sums in tap order
   int code[5];
@@ -261,11 +264,15 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
     const bool ok = t < taps && pp >= 0 && pp < seq_in;
     if (ok) mask |= 1u << t;
     code[t] = ok ? cc[in0 + t] : 0;
+    // zero_code: a combination whose table rows are all zero (the padding character: zero embedding rows) adds nothing,
+    // so its rows are not read.  Layer 0 computes up to 8 positions past a word's end for the layers above it, and every
+    // tap of theirs that falls on padding would fetch 2 KB of zeros: 70 % of the look-ups at a mean word length of 5.
+    if (ok && code[t] != zero_code) ldm |= 1u << t;
   }
   float4 va[5], vb[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
-    if ((mask >> t) & 1u) {
+    if ((ldm >> t) & 1u) {
       const float* tp = T + ((size_t)t * n_combo + code[t]) * F + c4;
       va[t] = *reinterpret_cast<const float4*>(tp);
       vb[t] = *reinterpret_cast<const float4*>(tp + half);
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   }
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
-    if ((mask >> t) & 1u) {
+    if ((ldm >> t) & 1u) {
       a.x += va[t].x; a.y += va[t].y; a.z += va[t].z; a.w += va[t].w;
       b.x += vb[t].x; b.y += vb[t].y; b.z += vb[t].z; b.w += vb[t].w;
     }
@@ -582,7 +589,7 @@ extern "C" int cube_ext_finish(const float* acc, int ld_acc, int B, int L, int r
 }
 
 static int conv0_lookup_entry(bool i8, const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                              const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                              const cube_conv_groups* groups, int taps, int half, int n_combo, int zero_code, void* out,
                               void* out_lo, int ld_out, void* stream) {
   if (i8 && !out_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup_i8: needs both planes");
   if (!T || !btab || !cc || !lang_word || !groups || !out) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: null pointer");
@@ -593,36 +600,38 @@ static int conv0_lookup_entry(bool i8, const float* T, const float* btab, const 
   const cube_conv_groups& cg = *groups;
   if (cg.n <= 0 || cg.n > CUBE_MAX_CONV_GROUPS) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: %d sequence groups", cg.n);
   int total = 0;
+  Conv0Ends ends = {};
   for (int g = 0; g < cg.n; ++g) {
     if (cg.seq_in[g] <= 0 || cg.n_rows[g] <= 0 || cg.n_rows[g] % cg.seq_in[g] || cg.seq_out[g] <= 0 ||
         cg.seq_out[g] > cg.seq_in[g] || cg.row0_out[g] != total || cg.row0_in[g] < 0 || cg.word0[g] < 0)
       CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: bad sequence group %d (output rows must be contiguous)", g);
     total += cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
+    ends.end[g] = total;
   }
   const int tpr = half / 4;
   const int rpb = tpr >= 256 ? 1 : 256 / tpr;
   if (tpr > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: half=%d too wide", half);
   if (i8)
     hipLaunchKernelGGL(conv0_lookup_kernel<true>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
-                       lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
+                       lang_word, cg, ends, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total, zero_code);
   else
     hipLaunchKernelGGL(conv0_lookup_kernel<false>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
-                       lang_word, cg, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total);
+                       lang_word, cg, ends, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total, zero_code);
   CUBE_CHECK_LAUNCH("cube_char_conv0_lookup");
   return CUBE_OK;
 }
 
 extern "C" int cube_char_conv0_lookup(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                                      const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                                      const cube_conv_groups* groups, int taps, int half, int n_combo, int zero_code, void* out,
                                       void* out_lo, int ld_out, void* stream) {
   CUBE_ENTRY();
-  return conv0_lookup_entry(false, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
+  return conv0_lookup_entry(false, T, btab, cc, lang_word, groups, taps, half, n_combo, zero_code, out, out_lo, ld_out, stream);
 }
 extern "C" int cube_char_conv0_lookup_i8(const float* T, const float* btab, const int32_t* cc, const int32_t* lang_word,
-                                         const cube_conv_groups* groups, int taps, int half, int n_combo, void* out,
+                                         const cube_conv_groups* groups, int taps, int half, int n_combo, int zero_code, void* out,
                                          void* out_lo, int ld_out, void* stream) {
   CUBE_ENTRY();
-  return conv0_lookup_entry(true, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream);
+  return conv0_lookup_entry(true, T, btab, cc, lang_word, groups, taps, half, n_combo, zero_code, out, out_lo, ld_out, stream);
 }
 
 extern "C" int cube_argmax_rows(const float* x, int ld, int col0, int n, int M, int32_t* out, void* stream) {

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
-ABI_VERSION = 17  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 18  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -111,11 +111,11 @@ SIGNATURES = {
     "cube_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,
-                                       c_int, c_void_p, c_void_p, c_int, c_void_p]),
+                                       c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "cube_masked_mean_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p]),
     "cube_char_conv0_lookup_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ConvGroups), c_int, c_int,
-                                          c_int, c_void_p, c_void_p, c_int, c_void_p]),
+                                          c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_split_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -169,6 +169,9 @@ def pack_conv0_tables(sd, prefix, tok_emb, case_emb, lang_emb, max_bytes=64 << 2
         bt = torch.einsum("mt,gtf->gmf", masks, contrib) + b.double()[None, None, :]            # [G, 32, F]
         out["T" + sfx] = T.float().contiguous()
         out["btab" + sfx] = bt.float().contiguous()
+    # the padding character (row 0 of both embeddings, zero under padding_idx = 0): if its table rows are exactly zero the
+    # kernel need not read them (cube_char_conv0_lookup, zero_code)
+    out["zero_code"] = 0 if all(float(out[k][:, 0, :].abs().max()) == 0.0 for k in ("T", "T_q")) else -1
     return out
 
 

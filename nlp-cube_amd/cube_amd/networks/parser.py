@@ -485,7 +485,7 @@ class _HipNet:
                     fn = lib.cube_char_conv0_lookup_i8 if i8 else lib.cube_char_conv0_lookup
                     hip.check(fn(l0["T"].data_ptr(), l0["btab"].data_ptr(), bt["char_idx"].data_ptr(),
                                  bt["lang_word"].data_ptr(), ctypes.pointer(bt["conv_groups"][0]),
-                                 l0["taps"], l0["half"], l0["n_combo"], gl[0].hi.data_ptr(),
+                                 l0["taps"], l0["half"], l0["n_combo"], l0.get("zero_code", -1), gl[0].hi.data_ptr(),
                                  lo(gl[0].lo), lay.xc_w, st), "cube_char_conv0_lookup")
                 src, src_ld = gl[0], lay.xc_w
                 continue

@@ -254,14 +254,16 @@ class TraceLib:
             self._need("masked_mean " + nm, p, 2 * ((N - 1) * ld_out + C), 2)
         return 0
 
-    def cube_char_conv0_lookup_i8(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream):
+    def cube_char_conv0_lookup_i8(self, T, btab, cc, lang_word, groups, taps, half, n_combo, zero_code, out, out_lo, ld_out,
+                                  stream):
         assert out_lo is not None
-        return self.cube_char_conv0_lookup(T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream,
-                                           esz=1)
+        return self.cube_char_conv0_lookup(T, btab, cc, lang_word, groups, taps, half, n_combo, zero_code, out, out_lo, ld_out,
+                                           stream, esz=1)
 
-    def cube_char_conv0_lookup(self, T, btab, cc, lang_word, groups, taps, half, n_combo, out, out_lo, ld_out, stream,
+    def cube_char_conv0_lookup(self, T, btab, cc, lang_word, groups, taps, half, n_combo, zero_code, out, out_lo, ld_out, stream,
                                esz=2):
         cg = groups.contents
+        assert -1 <= zero_code < n_combo
         self.calls.append(("conv0_lookup", cg.n, half))
         assert taps in (1, 3, 5) and half % 4 == 0 and ld_out >= half and 1 <= cg.n <= 32
         total = n_in = n_words = 0

@@ -837,6 +837,27 @@ def test_process_edge_documents(dev):
         assert diff == 0, (diff, len(got))  # measured: identical text (a near-tie flip here would need its margin shown)
 
 
+def test_padding_look_ups_skipped_in_the_first_character_layer_change_nothing(dev):
+    """cube_char_conv0_lookup with zero_code = the padding character (its table rows are zero: they are not read) gives
+    bit-identical scores to zero_code = -1 (every row read)."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    case = cases.FULL
+    p, cfg, enc, sd = _model(dev, case, "bf16x3")
+    l0 = p._pk["char_l0"]
+    assert l0["zero_code"] == 0  # zero embedding rows under padding_idx = 0 (modules.py:431-432)
+    doc = synth.make_document(enc, [3, 9, 1, 17, 6, 12], seed=5, ext_word_emb=case["ext"])
+    X = MorphoCollate(enc).collate_fn(doc.sentences, targets=False)
+    r1 = p.decode_batch(X)
+    a1, u1 = r1["arc_logits"].clone(), r1["upos_logits"].clone()
+    l0["zero_code"] = -1
+    try:
+        r2 = p.decode_batch(X)
+        assert torch.equal(a1, r2["arc_logits"]) and torch.equal(u1, r2["upos_logits"])
+    finally:
+        l0["zero_code"] = 0
+
+
 def test_repeated_words_share_one_character_cnn_row(dev):
     """`Parser.dedup_words` (the C featuriser hands every (spelling, language) pair of a batch to the character CNN
     once; the other occurrences copy its char-level vector): the five result columns AND the scores are bit-identical
