@@ -148,21 +148,25 @@ __global__ __launch_bounds__(256) void masked_mean_vec_kernel(MeanLayers ly, int
         make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
 }
 
-// int8x2 layers (cube_hip.h): 16 channels (16 bytes per plane) per thread; the sum over the positions
-// of a word is exact in int32
+// int8x2 layers (cube_hip.h): 16 channels (16 bytes per plane) of one word in one LAYER per lane -- eight adjacent lanes take
+// the (up to eight) layers of a (word, channel chunk) and the layer terms are added in layer order by lane shuffles, exactly
+// the order of the loop they replace (one thread per (word, chunk) walking the layers: 131k threads for 8192 words, a
+// quarter of the chip's wave slots, each a chain of dependent loads: 37 us; now .. us).  The sum over the positions of a word
+// is exact in int32.
 __global__ __launch_bounds__(256) void masked_mean_i8_kernel(MeanLayers ly, int ld_x, const int32_t* len, int N, int W,
                                                              int C, uint16_t* out, uint16_t* out_lo, int ld_out,
                                                              const int32_t* word_rows) {
   const int nchunk = C >> 4;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;  // (word, chunk); whole groups of eight lanes leave together
+  const int k = threadIdx.x & 7;                                // layer
   if (t >= N * nchunk) return;
   const int n = t / nchunk, c = (t - n * nchunk) << 4;
   const int l = min(max(len[n], 0), W);
   const float den = (float)max(len[n], 1);
-  float s[16];
+  float term[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) s[j] = 0.f;
-  for (int k = 0; k < ly.n; ++k) {
+  for (int j = 0; j < 16; ++j) term[j] = 0.f;
+  if (k < ly.n) {
     const size_t base = (size_t)(word_rows ? word_rows[(size_t)k * N + n] : n * W) * ld_x + c;  // bytes
     const unsigned char* hi = reinterpret_cast<const unsigned char*>(ly.hi[k]) + base;
     const unsigned char* lo = reinterpret_cast<const unsigned char*>(ly.lo[k]) + base;
@@ -191,25 +195,30 @@ __global__ __launch_bounds__(256) void masked_mean_i8_kernel(MeanLayers ly, int 
       }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s[j] += ly.weight[k] * ((float)sk[j] * (1.0f / (float)CUBE_I8_ONE));
+    for (int j = 0; j < 16; ++j) term[j] = (float)sk[j] * (1.0f / (float)CUBE_I8_ONE);
   }
-  uint16_t h[16], lw[16];
+  // s = fma(w_k, term_k, s) for k = 0 .. n-1 in layer order: every lane of the group runs the same chain on the shuffled terms
+  float s[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float v = s[j] / den;
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  const int lane0 = (threadIdx.x & 63) & ~7;
+  for (int kk = 0; kk < ly.n; ++kk) {
+    const float wk = ly.weight[kk];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = fmaf(wk, __shfl(term[j], lane0 + kk), s[j]);
+  }
+  if (k >= 2) return;  // lanes 0 and 1 of the group store 8 channels each
+  uint16_t h[8], lw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (k ? s[8 + j] : s[j]) / den;
     if (out_lo) split_bf16(v, h[j], lw[j]); else h[j] = f32_to_bf16(v);
   }
-  const size_t o = (size_t)n * ld_out + c;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const uint16_t* hh = h + 8 * half;
-    const uint16_t* ll = lw + 8 * half;
-    *reinterpret_cast<uint4*>(out + o + 8 * half) =
-        make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
-    if (out_lo)
-      *reinterpret_cast<uint4*>(out_lo + o + 8 * half) =
-          make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
-  }
+  const size_t o = (size_t)n * ld_out + c + 8 * k;
+  *reinterpret_cast<uint4*>(out + o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  if (out_lo)
+    *reinterpret_cast<uint4*>(out_lo + o) =
+        make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
 }
 
 __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int ld_acc, int B, int L, int root, int P, float K, int parts,
@@ -546,7 +555,7 @@ static int masked_mean_entry(bool i8, const void* const* x_hi, const void* const
   if (i8) {
     if (!x_lo || !vec || C % 16 || ld_x % 16) CUBE_FAIL(CUBE_ERR_ALIGN, "cube_masked_mean_i8: both planes, C and ld_x multiples of 16, 16-byte aligned pointers");
     for (int k = 0; k < n_layers; ++k) if (!ly.lo[k]) CUBE_FAIL(CUBE_ERR_ARG, "cube_masked_mean_i8: null lo plane %d", k);
-    hipLaunchKernelGGL(masked_mean_i8_kernel, dim3((N * (C / 16) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
+    hipLaunchKernelGGL(masked_mean_i8_kernel, dim3((N * (C / 16) * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
                        len, N, W, C, (uint16_t*)out, (uint16_t*)out_lo, ld_out, word_rows);
   } else if (vec)
     hipLaunchKernelGGL(masked_mean_vec_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, (hipStream_t)stream, ly, ld_x,
