@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void ext_finish_kernel(const float* acc, int l
 // first output row past each sequence group, computed by the host: the kernel's row -> group search is then compares only (a
 // loop with an integer division per group and thread was most of the kernel's time: 78.9 -> .. us per launch)
 struct Conv0Ends { int end[CUBE_MAX_CONV_GROUPS]; };
-template <bool I8>
+template <bool I8, int NV>  // NV quads of channels per thread: the row's index arithmetic and code loads are paid once per 4 * NV channels
 __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restrict__ T, const float* __restrict__ btab,
                                                            const int32_t* __restrict__ cc, const int32_t* __restrict__ lang_word,
                                                            const cube_conv_groups cg, const Conv0Ends ce, int taps, int half, int n_combo,
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   const int r_local = threadIdx.x / tpr;
   const int row = blockIdx.x * rpb + r_local;
   if (r_local >= rpb || row >= total_rows) return;
-  const int c4 = (threadIdx.x - r_local * tpr) * 4;
+  const int c0 = (threadIdx.x - r_local * tpr) * 4 * NV;
   int g = 0;
 #pragma unroll
   for (int i = 0; i < CUBE_MAX_CONV_GROUPS - 1; ++i) g += (i < cg.n - 1 && row >= ce.end[i]) ? 1 : 0;  // ends are non-decreasing
@@ -262,10 +262,9 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
   const int rel = row - cg.row0_out[g];
   const int j = rel / seq_out, pos = rel - j * seq_out;
   const int in0 = cg.row0_in[g] + j * seq_in + pos - (taps >> 1);
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   unsigned mask = 0, ldm = 0;  // taps inside the sequence (selects the bias row) / taps whose table row is read
   const size_t F = 2 * (size_t)half;
-  // all character codes first, then all table rows (ten 16-byte loads in flight), then the sums in tap order
+  // all character codes first, then all table rows (16-byte loads, all in flight), then the sums in tap order
   int code[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
@@ -278,50 +277,58 @@ __global__ __launch_bounds__(256) void conv0_lookup_kernel(const float* __restri
     // tap of theirs that falls on padding would fetch 2 KB of zeros: 70 % of the look-ups at a mean word length of 5.
     if (ok && code[t] != zero_code) ldm |= 1u << t;
   }
-  float4 va[5], vb[5];
+  float4 va[5][NV], vb[5][NV];
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
     if ((ldm >> t) & 1u) {
-      const float* tp = T + ((size_t)t * n_combo + code[t]) * F + c4;
-      va[t] = *reinterpret_cast<const float4*>(tp);
-      vb[t] = *reinterpret_cast<const float4*>(tp + half);
+      const float* tp = T + ((size_t)t * n_combo + code[t]) * F + c0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        va[t][v] = *reinterpret_cast<const float4*>(tp + 4 * v);
+        vb[t][v] = *reinterpret_cast<const float4*>(tp + half + 4 * v);
+      }
     }
   }
+  const float* bp = btab + ((size_t)lang_word[cg.word0[g] + j] * 32 + mask) * F + c0;
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    if ((ldm >> t) & 1u) {
-      a.x += va[t].x; a.y += va[t].y; a.z += va[t].z; a.w += va[t].w;
-      b.x += vb[t].x; b.y += vb[t].y; b.z += vb[t].z; b.w += vb[t].w;
+  for (int v = 0; v < NV; ++v) {
+    const int c4 = c0 + 4 * v;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      if ((ldm >> t) & 1u) {
+        a.x += va[t][v].x; a.y += va[t][v].y; a.z += va[t][v].z; a.w += va[t][v].w;
+        b.x += vb[t][v].x; b.y += vb[t][v].y; b.z += vb[t][v].z; b.w += vb[t][v].w;
+      }
+    }
+    const float4 ba = *reinterpret_cast<const float4*>(bp + 4 * v);
+    const float4 bb = *reinterpret_cast<const float4*>(bp + half + 4 * v);
+    const float gv[4] = {tanhf_(a.x + ba.x) * sigmoidf_(b.x + bb.x), tanhf_(a.y + ba.y) * sigmoidf_(b.y + bb.y),
+                         tanhf_(a.z + ba.z) * sigmoidf_(b.z + bb.z), tanhf_(a.w + ba.w) * sigmoidf_(b.w + bb.w)};
+    if constexpr (I8) {  // int8x2 planes (cube_hip.h): q = round(g * CUBE_I8_ONE) = 256*hi + lo
+      uint32_t ph = 0, pl = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int q = __float2int_rn(gv[k] * (float)CUBE_I8_ONE);
+        q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
+        const int hq = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
+        ph |= (uint32_t)(hq & 0xff) << (8 * k);
+        pl |= (uint32_t)((q - (hq << CUBE_I8_SHIFT)) & 0xff) << (8 * k);
+      }
+      const size_t ob = (size_t)row * ld_out + c4;  // bytes
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + ob) = ph;
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out_lo) + ob) = pl;
+    } else {
+      uint16_t h[4], l[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (out_lo) split_bf16(gv[k], h[k], l[k]); else h[k] = f32_to_bf16(gv[k]);
+      }
+      const size_t o = (size_t)row * ld_out + c4;
+      *reinterpret_cast<uint2*>(out + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+      if (out_lo) *reinterpret_cast<uint2*>(out_lo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
     }
   }
-  const float* bp = btab + ((size_t)lang_word[cg.word0[g] + j] * 32 + mask) * F + c4;
-  const float4 ba = *reinterpret_cast<const float4*>(bp);
-  const float4 bb = *reinterpret_cast<const float4*>(bp + half);
-  const float gv[4] = {tanhf_(a.x + ba.x) * sigmoidf_(b.x + bb.x), tanhf_(a.y + ba.y) * sigmoidf_(b.y + bb.y),
-                       tanhf_(a.z + ba.z) * sigmoidf_(b.z + bb.z), tanhf_(a.w + ba.w) * sigmoidf_(b.w + bb.w)};
-  if constexpr (I8) {  // int8x2 planes (cube_hip.h): q = round(g * CUBE_I8_ONE) = 256*hi + lo
-    uint32_t ph = 0, pl = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int q = __float2int_rn(gv[k] * (float)CUBE_I8_ONE);
-      q = q > CUBE_I8_ONE ? CUBE_I8_ONE : (q < -CUBE_I8_ONE ? -CUBE_I8_ONE : q);
-      const int hq = (q + (1 << (CUBE_I8_SHIFT - 1))) >> CUBE_I8_SHIFT;
-      ph |= (uint32_t)(hq & 0xff) << (8 * k);
-      pl |= (uint32_t)((q - (hq << CUBE_I8_SHIFT)) & 0xff) << (8 * k);
-    }
-    const size_t ob = (size_t)row * ld_out + c4;  // bytes
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + ob) = ph;
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out_lo) + ob) = pl;
-    return;
-  }
-  uint16_t h[4], l[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (out_lo) split_bf16(gv[k], h[k], l[k]); else h[k] = f32_to_bf16(gv[k]);
-  }
-  const size_t o = (size_t)row * ld_out + c4;
-  *reinterpret_cast<uint2*>(out + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  if (out_lo) *reinterpret_cast<uint2*>(out_lo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
 // ---- arg-max (first maximal index, like torch.argmax / numpy.argmax): one wave per row
@@ -617,15 +624,22 @@ static int conv0_lookup_entry(bool i8, const float* T, const float* btab, const 
     total += cg.n_rows[g] / cg.seq_in[g] * cg.seq_out[g];
     ends.end[g] = total;
   }
-  const int tpr = half / 4;
+  // two quads of channels per thread when the row is wide enough for half a wave of such threads (65.1 -> 57.1 us per launch;
+  // four quads: 82.9, the 40 table loads in flight cost the occupancy)
+#ifndef CUBE_CONV0_NV
+#define CUBE_CONV0_NV 2
+#endif
+  const int nv = (CUBE_CONV0_NV == 2 && half % 8 == 0 && half / 8 >= 32) ? 2 : 1;
+  const int tpr = half / (4 * nv);
   const int rpb = tpr >= 256 ? 1 : 256 / tpr;
   if (tpr > 256) CUBE_FAIL(CUBE_ERR_ARG, "cube_char_conv0_lookup: half=%d too wide", half);
-  if (i8)
-    hipLaunchKernelGGL(conv0_lookup_kernel<true>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
-                       lang_word, cg, ends, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total, zero_code);
-  else
-    hipLaunchKernelGGL(conv0_lookup_kernel<false>, dim3((total + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, T, btab, cc,
-                       lang_word, cg, ends, taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total, zero_code);
+  const dim3 grid((total + rpb - 1) / rpb), block(256);
+#define CONV0_LAUNCH(I8_, NV_)                                                                                          \
+  hipLaunchKernelGGL((conv0_lookup_kernel<I8_, NV_>), grid, block, 0, (hipStream_t)stream, T, btab, cc, lang_word, cg, ends, \
+                     taps, half, n_combo, (uint16_t*)out, (uint16_t*)out_lo, ld_out, tpr, rpb, total, zero_code)
+  if (i8) { if (nv == 2) CONV0_LAUNCH(true, 2); else CONV0_LAUNCH(true, 1); }
+  else { if (nv == 2) CONV0_LAUNCH(false, 2); else CONV0_LAUNCH(false, 1); }
+#undef CONV0_LAUNCH
   CUBE_CHECK_LAUNCH("cube_char_conv0_lookup");
   return CUBE_OK;
 }
