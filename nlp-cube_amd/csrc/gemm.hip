@@ -68,6 +68,9 @@ struct CfgSmall160 { static constexpr int BM = 160, BN = 128, WM = 5, WN = 2, SR
 struct CfgI8 { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, SR = 352, NB = 4; };
 
 constexpr int MAX_TAPS = 5;
+#ifndef CUBE_AOFF_SELECT
+#define CUBE_AOFF_SELECT 1
+#endif
 #ifndef CUBE_EPI_PREFETCH
 #define CUBE_EPI_PREFETCH 1
 #endif
@@ -365,10 +368,17 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     int aoff[TM], alo[TM];  // LDS byte offsets of this lane's A fragment (k-substep 0) and hi->lo distance
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const bool ok = (vmask[i] >> tap) & 1u;
       const int row = a_row[i] + tap;  // slab row of this lane's output row shifted by the tap
+#if CUBE_AOFF_SELECT
+      // branch-free: the compiler turns the conditional form into two divergent branches at the top of every k-step
+      const int okm = -(int)((vmask[i] >> tap) & 1u);
+      aoff[i] = ZERO_OFF + (((kc & 1) * A_BUF + lds_off(row, lh) - ZERO_OFF) & okm);
+      alo[i] = A_PLANE & okm;
+#else
+      const bool ok = (vmask[i] >> tap) & 1u;
       aoff[i] = ok ? (kc & 1) * A_BUF + lds_off(row, lh) : ZERO_OFF;
       alo[i] = ok ? A_PLANE : 0;
+#endif
     }
     // AD = how many units the activation fragments run ahead.  The int8x2 tile's units are short (6 MFMAs)
     // and two waves' reads queue in front of each other: two units ahead, and the second k-substep's
