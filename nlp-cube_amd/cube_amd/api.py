@@ -23,7 +23,7 @@ from cube_amd.io_utils.config import LemmatizerConfig, ParserConfig, TokenizerCo
 from cube_amd.io_utils.encodings import Encodings
 from cube_amd.io_utils.objects import Document
 from cube_amd.networks.lemmatizer import Lemmatizer, Word2TargetCollate
-from cube_amd.networks.lm import LMHelperDummy, LMHelperHF, LMHelperPrecomputed
+from cube_amd.networks.lm import LMHelperDummy, LMHelperFT, LMHelperHF, LMHelperPrecomputed
 from cube_amd.networks.parser import Parser
 from cube_amd.networks.tokenizer import Tokenizer
 from cube_amd.networks.utils import MorphoCollate
@@ -74,9 +74,9 @@ class CubeObj:
             # it must be a local directory (or pass lm_helper=LMHelperHF(device, splitter=..., encoder=...) with loaded objects)
             self._lm_helper = LMHelperHF(device=device, model=str(config.lm_model).split(":")[-1])
         else:
-            raise NotImplementedError(
-                "lm_model '%s' needs a fastText model (api.py:97-98; not rebuilt, SURVEY.md §8f); pass "
-                "lm_helper=LMHelperPrecomputed(sizes) and set word.emb yourself" % config.lm_model)
+            # reference: api.py:97-98.  Needs the fasttext package and ~/.fasttext/cc.<lang>.300.bin (never downloaded here);
+            # otherwise pass lm_helper=LMHelperFT(fasttext_model=...) or LMHelperPrecomputed(sizes)
+            self._lm_helper = LMHelperFT(model=str(config.lm_model).split(":")[-1])
         encodings = Encodings()
         encodings.load("{0}.encodings".format(path))
         self._parser = Parser(config, encodings, language_codes=g_conf["language_codes"],

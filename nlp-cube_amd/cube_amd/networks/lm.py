@@ -4,9 +4,10 @@
 caller's (HuggingFace objects loaded from local files, or any objects with the same two calls -- no model can be
 fetched here, so none is named by default); what this module owns is the part of `_compute_we` around the model
 call: piece bookkeeping, the 512-piece windows, and the sub-word -> word pooling with the cut into per-layer vectors,
-which runs on the device (csrc/pool.hip, `cube_subword_pool`) on the hidden states where the model left them.  The
-fastText / Languasito providers (lm.py:34-118) need model files and stay the caller's; `LMHelperDummy` and
-`LMHelperPrecomputed` are the model-free ones.
+which runs on the device (csrc/pool.hip, `cube_subword_pool`) on the hidden states where the model left them.
+`LMHelperFT` mirrors the fastText provider (lm.py:34-66) around a loaded fastText model; the Languasito provider
+(lm.py:69-118) needs a package that is not here and stays the caller's; `LMHelperDummy` and `LMHelperPrecomputed` are the
+model-free ones.
 """
 import ctypes
 
@@ -29,6 +30,37 @@ class LMHelperDummy:
 
     def apply_raw(self, batch):
         return [[[1.0] for _ in sent] for sent in batch]
+
+
+class LMHelperFT:
+    """reference: lm.py:34-66 -- one 300-wide fastText vector per word.  `fasttext_model`: a loaded fastText model (any object
+    with `get_word_vector(str)`); without it the reference's file `~/.fasttext/cc.<model>.300.bin` is loaded when the
+    `fasttext` package and the file are present -- nothing is downloaded (the reference fetches the model, lm.py:41-48;
+    there is no network here).  The look-up itself is the fastText library's: host code, not part of the device path."""
+
+    def __init__(self, device="cpu", model=None, fasttext_model=None):
+        if fasttext_model is None:
+            import os
+            filename = os.path.join(os.path.expanduser("~"), ".fasttext", "cc.%s.300.bin" % model)
+            try:
+                import fasttext
+            except ImportError as e:
+                raise NotImplementedError("LMHelperFT needs the fasttext package or a loaded model (fasttext_model=...)") from e
+            if not os.path.exists(filename):
+                raise FileNotFoundError("%s is missing and cannot be downloaded here (lm.py:41-48 would fetch it)" % filename)
+            fasttext_model = fasttext.load_model(filename)
+        self._fasttext = fasttext_model
+
+    def get_embedding_size(self):
+        return [300]
+
+    def apply(self, document):
+        for sent in document.sentences:
+            for w in sent.words:
+                w.emb = [self._fasttext.get_word_vector(w.word)]
+
+    def apply_raw(self, batch):
+        return [[self._fasttext.get_word_vector(w) for w in sent] for sent in batch]
 
 
 class LMHelperPrecomputed:

@@ -31,3 +31,28 @@ def test_pooling_oracle_equals_reference(golden_dir):
         words = [w]
     got = lm_oracle.compute_we([S], split, model)[0]
     np.testing.assert_array_equal(got, ((hs[1] + hs[1]) + hs[2]) / 3)
+
+
+def test_fasttext_helper_mirrors_the_reference_calls():
+    """LMHelperFT (lm.py:34-66) around an injected model: one vector per word in `apply`, nested lists in `apply_raw`;
+    without a model, the fasttext package or the model file it says so instead of downloading."""
+    import numpy as np
+    import pytest
+    from cube_amd import synth
+    from cube_amd.networks.lm import LMHelperFT
+
+    class Model:
+        def get_word_vector(self, w):
+            return np.full(300, float(len(w)), dtype=np.float32)
+
+    h = LMHelperFT(fasttext_model=Model())
+    assert h.get_embedding_size() == [300]
+    doc = synth.make_document(synth.make_encodings(), [3, 1], seed=2)
+    h.apply(doc)
+    for s_ in doc.sentences:
+        for w in s_.words:
+            assert len(w.emb) == 1 and w.emb[0].shape == (300,) and w.emb[0][0] == len(w.word)
+    raw = h.apply_raw([["ab", "c"], ["def"]])
+    assert [len(x) for x in raw] == [2, 1] and raw[1][0][0] == 3.0
+    with pytest.raises((NotImplementedError, FileNotFoundError)):
+        LMHelperFT(model="xx")
