@@ -1228,12 +1228,56 @@ static PyObject* max_words(PyObject* self, PyObject* args) {
   return PyLong_FromSsize_t(mx);
 }
 
-/* geometry(sentences) -> (int32 [n] words per sentence, int32 [n] longest word per sentence): what decides the
- * padding of a reference batch (longest sentence, longest word), for merging reference batches of equal geometry
- * (cube_amd/sharding.py) without a Python-level pass over every word. */
+/* geometry(sentences[, n_threads]) -> (int32 [n] words per sentence, int32 [n] longest word per sentence): what decides
+ * the padding of a reference batch (longest sentence, longest word), for merging reference batches of equal geometry
+ * (cube_amd/sharding.py) without a Python-level pass over every word.  This pass runs BEFORE the first batch of a
+ * document can be enqueued (nothing overlaps it), so plain-format documents (every Word of one class with `word` in
+ * __slots__, exact str) are read on the thread pool, as featurize reads them: the GIL is held by the caller, the workers
+ * only read object memory. */
+typedef struct {
+  Py_ssize_t n;
+  PyObject** lists;  /* [n] the sentences' word lists (borrowed; the sentences keep them) */
+  PyTypeObject* tp;
+  Py_ssize_t off_word;
+  int32_t* wmax;
+  volatile int fallback;
+} GeoCtx;
+
+static void par_geometry(void* vctx, int chunk, int n_chunks) {
+  GeoCtx* c = (GeoCtx*)vctx;
+  const Py_ssize_t b0 = c->n * chunk / n_chunks, b1 = c->n * (chunk + 1) / n_chunks;
+  enum { SPAN = 64 };
+  PyObject* strs[SPAN];
+  for (Py_ssize_t b = b0; b < b1; ++b) {
+    if (b + 1 < b1) __builtin_prefetch(((PyListObject*)c->lists[b + 1])->ob_item);
+    const Py_ssize_t m = PyList_GET_SIZE(c->lists[b]);
+    PyObject** items = ((PyListObject*)c->lists[b])->ob_item;
+    Py_ssize_t mx = 0;
+    for (Py_ssize_t j0 = 0; j0 < m; j0 += SPAN) { /* Word -> str -> length in sweeps, each level prefetched by the one before */
+      const Py_ssize_t k = m - j0 < SPAN ? m - j0 : SPAN;
+      for (Py_ssize_t j = 0; j < k; ++j) __builtin_prefetch((char*)items[j0 + j] + c->off_word);
+      for (Py_ssize_t j = 0; j < k; ++j) {
+        PyObject* o = items[j0 + j];
+        if (Py_TYPE(o) != c->tp) { c->fallback = 1; return; }
+        PyObject* t = *(PyObject**)((char*)o + c->off_word);
+        if (!t) { c->fallback = 1; return; }
+        strs[j] = t;
+        __builtin_prefetch(t);
+      }
+      for (Py_ssize_t j = 0; j < k; ++j) {
+        PyObject* t = strs[j];
+        if (!PyUnicode_CheckExact(t) || !PyUnicode_IS_READY(t)) { c->fallback = 1; return; }
+        if (PyUnicode_GET_LENGTH(t) > mx) mx = PyUnicode_GET_LENGTH(t);
+      }
+    }
+    c->wmax[b] = (int32_t)(mx > 0x7fffffff ? 0x7fffffff : mx);
+  }
+}
+
 static PyObject* geometry(PyObject* self, PyObject* args) {
   PyObject* sents;
-  if (!PyArg_ParseTuple(args, "O!", &PyList_Type, &sents)) return NULL;
+  int n_threads = 1;
+  if (!PyArg_ParseTuple(args, "O!|i", &PyList_Type, &sents, &n_threads)) return NULL;
   const Py_ssize_t n = PyList_GET_SIZE(sents);
   npy_intp dims[1] = {(npy_intp)n};
   PyArrayObject* a_len = (PyArrayObject*)PyArray_ZEROS(1, dims, NPY_INT32, 0);
@@ -1243,6 +1287,39 @@ static PyObject* geometry(PyObject* self, PyObject* args) {
   int32_t* pw = (int32_t*)PyArray_DATA(a_wmax);
   WordLayout wl;
   wl.tp = NULL;
+  if (n_threads > 1 && n >= 512) { /* the plain format on the pool; anything unusual falls through to the serial pass below */
+    PyObject** lists = (PyObject**)malloc(sizeof(PyObject*) * (size_t)n);
+    if (!lists) { Py_DECREF(a_len); Py_DECREF(a_wmax); return PyErr_NoMemory(); }
+    int ok = 1;
+    PyObject* first = NULL;
+    for (Py_ssize_t b = 0; ok && b < n; ++b) {
+      PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+      if (!ws) { PyErr_Clear(); ok = 0; break; }
+      if (!PyList_CheckExact(ws) || Py_REFCNT(ws) < 2) ok = 0; /* a list made for this call would not outlive the DECREF below */
+      else {
+        lists[b] = ws;
+        pl[b] = (int32_t)PyList_GET_SIZE(ws);
+        if (!first && PyList_GET_SIZE(ws) > 0) first = PyList_GET_ITEM(ws, 0);
+      }
+      Py_DECREF(ws); /* the sentence keeps its list; no Python code runs until the pool is done */
+    }
+    if (ok && first) {
+      word_layout(Py_TYPE(first), &wl);
+      if (wl.off[F_WORD] >= 0) {
+        GeoCtx gc;
+        gc.n = n; gc.lists = lists; gc.tp = Py_TYPE(first); gc.off_word = wl.off[F_WORD]; gc.wmax = pw; gc.fallback = 0;
+        int nch = 4 * n_threads;
+        if (nch > 64) nch = 64;
+        if (nch > n / 64) nch = (int)(n / 64);
+        pool_run(par_geometry, &gc, nch, n_threads);
+        if (!gc.fallback) {
+          free(lists);
+          return Py_BuildValue("(NN)", (PyObject*)a_len, (PyObject*)a_wmax);
+        }
+      }
+    }
+    free(lists);
+  }
   for (Py_ssize_t b = 0; b < n; ++b) {
     PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
     if (!ws || !PyList_Check(ws)) {

@@ -31,6 +31,9 @@ from cube_amd.networks.packing import p32, p128
 from cube_amd.networks.utils import MorphoCollate, MorphoDataset, ChuLiuEdmondsDecoder  # noqa: F401
 
 
+_STAGE_STREAMS = {}   # (device type, index) -> the three stage streams shared by all models on that device (_init_pipeline)
+
+
 class _Buffers:
     """Grow-only, zero-initialised flat device buffers with fixed leading dimensions, so the
     padding columns no kernel writes stay zero for the life of the model.  bf16 buffers are
@@ -881,7 +884,14 @@ class Parser(_HipNet):
         # that land on one queue run one after the other.  A decode stream per slot was measured: 117k..159k
         # sentences/s depending on GPU_MAX_HW_QUEUES and on whether RCCL was loaded; one decode stream:
         # 154k..159k in all four combinations, and config 2 no slower (16.7k).
-        self._streams = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
+        # ... and the SAME three for every model of the process on this device: streams created later (a second Parser,
+        # a Tagger beside it) were seen to land two to a hardware queue, which runs their stages one after the other
+        # (pipelined rate = one-stream rate, scripts/batch_size_sweep.py before this); sharing streams between models only
+        # adds ordering between them.
+        key = (self._device.type, self._device.index)
+        if key not in _STAGE_STREAMS:
+            _STAGE_STREAMS[key] = tuple(torch.cuda.Stream(device=self._device) for _ in range(3))
+        self._streams = _STAGE_STREAMS[key]
         self._groups = [dict(free=None, host=None, pending=0, members=[], open=False, done=None) for _ in range(self.N_GROUPS)]
         self._open = None
         self._n_groups = 0

@@ -66,7 +66,7 @@ def sentence_batch_keys(sents, starts, batch_size, cap):
     if hm is not None and isinstance(sents, list) and len(starts) > 1 and \
             all(b - a == batch_size for a, b in zip(starts[:-1], starts[1:])) and starts[0] == 0:
         import numpy as np
-        slen, wmax = hm.geometry(sents)  # one C pass over the words (csrc/host_collate.c)
+        slen, wmax = hm.geometry(sents, 8)  # one C pass over the words, on the host thread pool (csrc/host_collate.c)
         idx = np.asarray(starts, dtype=np.int64)
         lmax = np.maximum.reduceat(slen, idx)
         wm = np.maximum.reduceat(wmax, idx)

@@ -20,6 +20,13 @@ for B in [int(a) for a in sys.argv[1:]] or [128, 256, 512, 712, 1024]:
     bench.run_steps(p, batches, n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("B = %4d: %.3f ms per batch, %.0f sentences/s" % (B, dt / n * 1e3, n * B / dt), flush=True)
+    bench.run_steps(p, batches, 4, serial=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bench.run_steps(p, batches, 8, serial=True)
+    torch.cuda.synchronize()
+    ds = (time.perf_counter() - t0) / 8
+    print("B = %4d: %.3f ms per batch, %.0f sentences/s   (one stream: %.3f ms per batch, %.0f sentences/s; in flight %d)"
+          % (B, dt / n * 1e3, n * B / dt, ds * 1e3, B / ds, p.in_flight_for(33)), flush=True)
     del p, batches
     torch.cuda.empty_cache()

@@ -95,6 +95,10 @@ dt = time.perf_counter() - t0
 sys.setprofile(None)
 print("process: %.1f ms for %d sentences = %.0f sentences/s, feature_thread=%s" % (dt * 1e3, len(big.sentences), len(big.sentences) / dt, p.feature_thread))
 subs = [e for e in log if e[1] == "submit"]
+print("submit calls at (ms since the start of process):", " ".join("%.1f" % ((e[2] - t0) * 1e3) for e in subs), "| end %.1f" % (dt * 1e3))
+for nm in ("_host_batch", "_upload", "submit", "collect", "_write_back"):
+    v = [e[3] - e[2] for e in log if e[1] == nm]
+    print("  %-12s %3d calls, %.2f ms total, first %.2f, last %.2f" % (nm, len(v), sum(v) * 1e3, v[0] * 1e3, v[-1] * 1e3))
 ta = subs[first][2]
 tb = subs[min(first + count, len(subs) - 1)][2]
 for th, name, s, e in sorted(log, key=lambda r: r[2]):

@@ -665,3 +665,34 @@ def test_batch_geometry_keys_c_equals_python(monkeypatch):
         slow = sharding.sentence_batch_keys(doc.sentences, starts, bs, cap)
         monkeypatch.undo()
         assert fast == slow, bs
+
+
+def test_geometry_on_the_thread_pool_equals_the_serial_pass():
+    """`geometry(sentences, n_threads)` reads plain-format documents on the pool (>= 512 sentences); ragged sentences, an
+    empty one, a word of another class (-> the serial pass) and a non-str word (-> the serial pass's TypeError)."""
+    from cube_amd import host
+    hm = host.load()
+    _, enc, _ = cases.parser_model(cases.TINY)
+    rng = np.random.default_rng(9)
+    doc = synth.make_document(enc, rng.integers(1, 40, size=1500), seed=6, ext_word_emb=(4,), max_word_len=14)
+    doc.sentences[17].words = []
+    want_len = np.array([len(s.words) for s in doc.sentences], dtype=np.int32)
+    want_max = np.array([max((len(w.word) for w in s.words), default=0) for s in doc.sentences], dtype=np.int32)
+    for nt in (1, 2, 8):
+        slen, wmax = hm.geometry(doc.sentences, nt)
+        assert (slen == want_len).all() and (wmax == want_max).all(), nt
+    slen, wmax = hm.geometry(doc.sentences)
+    assert (slen == want_len).all() and (wmax == want_max).all()
+
+    class Other:
+        def __init__(self, word):
+            self.word = word
+    w = doc.sentences[900].words[0]
+    doc.sentences[900].words[0] = Other("x" * 31)
+    want_max[900] = max(want_max[900], 31)
+    slen, wmax = hm.geometry(doc.sentences, 8)
+    assert (slen == want_len).all() and (wmax == want_max).all()
+    doc.sentences[900].words[0] = w
+    doc.sentences[1200].words[-1].word = 5
+    with pytest.raises(TypeError):
+        hm.geometry(doc.sentences, 8)
