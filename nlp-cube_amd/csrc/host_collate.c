@@ -136,8 +136,8 @@ static PyObject* fill_ragged(PyObject* self, PyObject* args) {
 #include <pthread.h>
 #include "../../include/cube_hip.h" /* cube_conv_groups, CUBE_MAX_CONV_GROUPS */
 
-enum { F_WORD = 0, F_EMB, F_HEAD, F_LABEL, F_UPOS, F_XPOS, F_ATTRS, F_COUNT };
-static const char* const FIELD_NAMES[F_COUNT] = {"word", "emb", "head", "label", "upos", "xpos", "attrs"};
+enum { F_WORD = 0, F_EMB, F_HEAD, F_LABEL, F_UPOS, F_XPOS, F_ATTRS, F_LEMMA, F_COUNT };
+static const char* const FIELD_NAMES[F_COUNT] = {"word", "emb", "head", "label", "upos", "xpos", "attrs", "lemma"};
 static PyObject* field_str[F_COUNT];
 static PyObject *str_words, *str_lang_id, *str_lower;
 
@@ -1408,6 +1408,161 @@ static PyObject* write_back(PyObject* self, PyObject* args) {
   Py_RETURN_NONE;
 }
 
+/* ---- Lemmatizer.process_bucketed: the two passes over every word of the document that nothing on the device overlaps ----
+ * lemma_keys(sentences, max_len) -> (words list, upos list, int32 lang_id [n_keys], int32 word length [n_keys], int32 key
+ * index [n_words]): the DISTINCT (word, upos, sentence.lang_id) triples of the words of at most `max_len` characters, in
+ * order of first appearance (what a dict keyed by the tuple gives: equal means equal by ==), and for every such word, in
+ * document order, the index of its triple.  Words longer than max_len are skipped (utils.py:109-110). */
+typedef struct { Py_hash_t h; int32_t idx; } KeySlot;
+
+static PyObject* lemma_keys(PyObject* self, PyObject* args) {
+  PyObject* sents;
+  Py_ssize_t max_len;
+  if (!PyArg_ParseTuple(args, "O!n", &PyList_Type, &sents, &max_len)) return NULL;
+  const Py_ssize_t B = PyList_GET_SIZE(sents);
+  Py_ssize_t N = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws) return NULL;
+    if (!PyList_Check(ws)) { Py_DECREF(ws); PyErr_SetString(PyExc_TypeError, "lemma_keys: sentence.words is not a list"); return NULL; }
+    N += PyList_GET_SIZE(ws);
+    Py_DECREF(ws);
+  }
+  if (N > 0x3fffffff) { PyErr_SetString(PyExc_ValueError, "lemma_keys: too many words"); return NULL; }
+  size_t cap = 64;
+  while (cap < 2 * (size_t)N) cap <<= 1;
+  KeySlot* tab = (KeySlot*)malloc(sizeof(KeySlot) * cap);
+  int32_t* widx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+  int32_t* klang = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+  PyObject* kwords = PyList_New(0);
+  PyObject* kupos = PyList_New(0);
+  PyObject* result = NULL;
+  Py_ssize_t n_words = 0, n_keys = 0;
+  WordLayout wl;
+  wl.tp = NULL;
+  if (!tab || !widx || !klang || !kwords || !kupos) { PyErr_NoMemory(); goto done; }
+  for (size_t i = 0; i < cap; ++i) tab[i].idx = -1;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* s = PyList_GET_ITEM(sents, b);
+    PyObject* lg = PyObject_GetAttr(s, str_lang_id);
+    if (!lg) goto done;
+    const long lang = PyLong_AsLong(lg);
+    Py_DECREF(lg);
+    if (lang == -1 && PyErr_Occurred()) goto done;
+    if (lang < -0x7fffffffL || lang > 0x7fffffffL) { PyErr_SetString(PyExc_ValueError, "lemma_keys: lang_id out of range"); goto done; }
+    PyObject* ws = PyObject_GetAttr(s, str_words);
+    if (!ws) goto done;
+    if (!PyList_Check(ws)) { Py_DECREF(ws); PyErr_SetString(PyExc_TypeError, "lemma_keys: sentence.words is not a list"); goto done; }
+    const Py_ssize_t m = PyList_GET_SIZE(ws);
+    if (n_words + m > N) { Py_DECREF(ws); PyErr_SetString(PyExc_ValueError, "lemma_keys: the document changed"); goto done; }
+    for (Py_ssize_t j = 0; j < m; ++j) {
+      if (j + 4 < m) __builtin_prefetch(PyList_GET_ITEM(ws, j + 4));
+      PyObject* w = PyList_GET_ITEM(ws, j);
+      PyObject* word = word_get(w, &wl, F_WORD);
+      if (!word) { Py_DECREF(ws); goto done; }
+      if (!PyUnicode_Check(word) || PyUnicode_READY(word) != 0) {
+        Py_DECREF(word); Py_DECREF(ws);
+        PyErr_SetString(PyExc_TypeError, "lemma_keys: word.word is not a str");
+        goto done;
+      }
+      if (PyUnicode_GET_LENGTH(word) > max_len) { Py_DECREF(word); continue; }
+      PyObject* upos = word_get(w, &wl, F_UPOS);
+      if (!upos) { Py_DECREF(word); Py_DECREF(ws); goto done; }
+      const Py_hash_t hw = PyObject_Hash(word), hu = PyObject_Hash(upos);
+      if ((hw == -1 || hu == -1) && PyErr_Occurred()) { Py_DECREF(word); Py_DECREF(upos); Py_DECREF(ws); goto done; }
+      const Py_hash_t h = (Py_hash_t)(((size_t)hw * 1000003u) ^ ((size_t)hu * 8191u) ^ ((size_t)lang * 2654435761u));
+      size_t pos = ((size_t)h ^ ((size_t)h >> 17)) & (cap - 1);
+      int32_t found = -1;
+      for (;;) {
+        const int32_t k = tab[pos].idx;
+        if (k < 0) break;
+        if (tab[pos].h == h && klang[k] == (int32_t)lang) {
+          PyObject* kw = PyList_GET_ITEM(kwords, k);
+          PyObject* ku = PyList_GET_ITEM(kupos, k);
+          int eq = kw == word ? 1 : PyObject_RichCompareBool(kw, word, Py_EQ);
+          if (eq > 0) eq = ku == upos ? 1 : PyObject_RichCompareBool(ku, upos, Py_EQ);
+          if (eq < 0) { Py_DECREF(word); Py_DECREF(upos); Py_DECREF(ws); goto done; }
+          if (eq) { found = k; break; }
+        }
+        pos = (pos + 1) & (cap - 1);
+      }
+      if (found < 0) {
+        if (PyList_Append(kwords, word) != 0 || PyList_Append(kupos, upos) != 0) { Py_DECREF(word); Py_DECREF(upos); Py_DECREF(ws); goto done; }
+        found = (int32_t)n_keys++;
+        klang[found] = (int32_t)lang;
+        tab[pos].h = h;
+        tab[pos].idx = found;
+      }
+      widx[n_words++] = found;
+      Py_DECREF(word);
+      Py_DECREF(upos);
+    }
+    Py_DECREF(ws);
+  }
+  {
+    npy_intp dk[1] = {(npy_intp)n_keys}, dw[1] = {(npy_intp)n_words};
+    PyArrayObject* a_lang = (PyArrayObject*)PyArray_SimpleNew(1, dk, NPY_INT32);
+    PyArrayObject* a_len = (PyArrayObject*)PyArray_SimpleNew(1, dk, NPY_INT32);
+    PyArrayObject* a_idx = (PyArrayObject*)PyArray_SimpleNew(1, dw, NPY_INT32);
+    if (!a_lang || !a_len || !a_idx) { Py_XDECREF(a_lang); Py_XDECREF(a_len); Py_XDECREF(a_idx); goto done; }
+    memcpy(PyArray_DATA(a_lang), klang, sizeof(int32_t) * (size_t)n_keys);
+    memcpy(PyArray_DATA(a_idx), widx, sizeof(int32_t) * (size_t)n_words);
+    int32_t* pl = (int32_t*)PyArray_DATA(a_len);
+    for (Py_ssize_t k = 0; k < n_keys; ++k) pl[k] = (int32_t)PyUnicode_GET_LENGTH(PyList_GET_ITEM(kwords, k));
+    result = Py_BuildValue("(OONNN)", kwords, kupos, (PyObject*)a_lang, (PyObject*)a_len, (PyObject*)a_idx);
+  }
+done:
+  free(tab); free(widx); free(klang);
+  Py_XDECREF(kwords); Py_XDECREF(kupos);
+  return result;
+}
+
+/* assign_lemmas(sentences, key index int32 [n_words], lemmas list [n_keys], max_len): word.lemma = lemmas[index] for the
+ * words of at most max_len characters, in the order lemma_keys saw them; the others keep their lemma. */
+static PyObject* assign_lemmas(PyObject* self, PyObject* args) {
+  PyObject *sents, *lemmas;
+  PyArrayObject* idx;
+  Py_ssize_t max_len;
+  if (!PyArg_ParseTuple(args, "O!O!O!n", &PyList_Type, &sents, &PyArray_Type, &idx, &PyList_Type, &lemmas, &max_len)) return NULL;
+  if (PyArray_TYPE(idx) != NPY_INT32 || PyArray_NDIM(idx) != 1 || !PyArray_IS_C_CONTIGUOUS(idx)) {
+    PyErr_SetString(PyExc_ValueError, "assign_lemmas: the key indices must be a C-contiguous int32 vector");
+    return NULL;
+  }
+  const int32_t* pi = (const int32_t*)PyArray_DATA(idx);
+  const Py_ssize_t n_idx = PyArray_DIM(idx, 0), n_keys = PyList_GET_SIZE(lemmas);
+  Py_ssize_t k = 0;
+  WordLayout wl;
+  wl.tp = NULL;
+  const Py_ssize_t B = PyList_GET_SIZE(sents);
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* ws = PyObject_GetAttr(PyList_GET_ITEM(sents, b), str_words);
+    if (!ws) return NULL;
+    if (!PyList_Check(ws)) { Py_DECREF(ws); PyErr_SetString(PyExc_TypeError, "assign_lemmas: sentence.words is not a list"); return NULL; }
+    for (Py_ssize_t j = 0; j < PyList_GET_SIZE(ws); ++j) {
+      if (j + 4 < PyList_GET_SIZE(ws)) __builtin_prefetch(PyList_GET_ITEM(ws, j + 4));
+      PyObject* w = PyList_GET_ITEM(ws, j);
+      int owned = 0;
+      PyObject* word = word_peek(w, &wl, F_WORD, &owned);
+      if (!word) { Py_DECREF(ws); return NULL; }
+      const int is_str = PyUnicode_Check(word) && PyUnicode_READY(word) == 0;
+      const Py_ssize_t len = is_str ? PyUnicode_GET_LENGTH(word) : 0;
+      if (owned) Py_DECREF(word);
+      if (!is_str) { Py_DECREF(ws); PyErr_SetString(PyExc_TypeError, "assign_lemmas: word.word is not a str"); return NULL; }
+      if (len > max_len) continue;
+      if (k >= n_idx || pi[k] < 0 || pi[k] >= n_keys) {
+        Py_DECREF(ws);
+        PyErr_SetString(PyExc_ValueError, "assign_lemmas: the document does not match the key indices");
+        return NULL;
+      }
+      if (word_set(w, &wl, F_LEMMA, PyList_GET_ITEM(lemmas, pi[k])) != 0) { Py_DECREF(ws); return NULL; }
+      ++k;
+    }
+    Py_DECREF(ws);
+  }
+  if (k != n_idx) { PyErr_SetString(PyExc_ValueError, "assign_lemmas: the document does not match the key indices"); return NULL; }
+  Py_RETURN_NONE;
+}
+
 
 static PyMethodDef methods[] = {
     {"stack_rows", stack_rows, METH_VARARGS, "copy N equal-size contiguous buffers into one [N, size] buffer"},
@@ -1419,6 +1574,8 @@ static PyMethodDef methods[] = {
     {"timing", timing, METH_NOARGS, "accumulated seconds per stage of featurize since the last call"},
     {"geometry", geometry, METH_VARARGS, "words per sentence and longest word per sentence"},
     {"max_words", max_words, METH_VARARGS, "word count of the longest sentence"},
+    {"lemma_keys", lemma_keys, METH_VARARGS, "distinct (word, upos, lang_id) triples of a document + the triple of every word"},
+    {"assign_lemmas", assign_lemmas, METH_VARARGS, "word.lemma = lemmas[key index] for the words lemma_keys listed"},
     {"write_back", write_back, METH_VARARGS, "result ids -> head / label / upos / xpos / attrs of every word"},
     {NULL, NULL, 0, NULL}};
 

@@ -401,32 +401,55 @@ class Lemmatizer:
         depend on batch composition.  Words longer than 25 characters keep their lemma (the
         reference's dataset skips them, utils.py:109-110, and then mis-assigns, lemmatizer.py:225-229)."""
         self._require_gpu()
-        keys, order, targets, widx = {}, [], [], []   # key -> index, keys by index, the words to fill, their key's index
-        for sent in doc.sentences:
-            lang = sent.lang_id
-            for w in sent.words:
-                word = w.word
-                if len(word) <= 25:
-                    k = (word, w.upos, lang)
-                    i = keys.get(k)
-                    if i is None:
-                        i = keys[k] = len(order)
-                        order.append(k)
-                    targets.append(w)
-                    widx.append(i)
-        lens = np.fromiter((len(k[0]) for k in order), dtype=np.int64, count=len(order))
+        from cube_amd import host
+        hm = host.load()
+        fast = None
+        if hm is not None and isinstance(doc.sentences, list):
+            # the two passes over every word run before / after all device work: one C pass each (csrc/host_collate.c)
+            try:
+                fast = hm.lemma_keys(doc.sentences, 25)
+            except TypeError:
+                fast = None   # unusual objects: the Python pass below says what is wrong, or handles them
+        if fast is not None:
+            k_word, k_upos, k_lang, lens, widx = fast
+            lens = lens.astype(np.int64)
+            n_keys = len(k_word)
+
+            def item(i):
+                return {"word": k_word[i], "upos": k_upos[i], "lang_id": int(k_lang[i]), "target": ""}
+        else:
+            keys, order, targets, widx = {}, [], [], []   # key -> index, keys by index, the words to fill, their key's index
+            for sent in doc.sentences:
+                lang = sent.lang_id
+                for w in sent.words:
+                    word = w.word
+                    if len(word) <= 25:
+                        k = (word, w.upos, lang)
+                        i = keys.get(k)
+                        if i is None:
+                            i = keys[k] = len(order)
+                            order.append(k)
+                        targets.append(w)
+                        widx.append(i)
+            lens = np.fromiter((len(k[0]) for k in order), dtype=np.int64, count=len(order))
+            n_keys = len(order)
+
+            def item(i):
+                return {"word": order[i][0], "upos": order[i][1], "lang_id": order[i][2], "target": ""}
         perm = np.argsort(lens, kind="stable")
         parts = []   # lists of key indices: equal word length, at most max_words each
         cuts = np.flatnonzero(np.diff(lens[perm])) + 1
         for seg in np.split(perm, cuts):
             parts += [seg[s:s + max_words].tolist() for s in range(0, len(seg), max_words)]
-        items = ([{"word": order[i][0], "upos": order[i][1], "lang_id": order[i][2], "target": ""} for i in part] for part in parts)
-        lemma_of = [None] * len(order)
-        for b, lemmas in self._decode_batches(items, collate):
+        lemma_of = [None] * n_keys
+        for b, lemmas in self._decode_batches(([item(i) for i in part] for part in parts), collate):
             for i, lemma in zip(parts[b], lemmas):
                 lemma_of[i] = lemma
-        for w, i in zip(targets, widx):
-            w.lemma = lemma_of[i]
+        if fast is not None:
+            hm.assign_lemmas(doc.sentences, widx, lemma_of, 25)
+        else:
+            for w, i in zip(targets, widx):
+                w.lemma = lemma_of[i]
         return doc
 
     @hip.on_device

@@ -696,3 +696,55 @@ def test_geometry_on_the_thread_pool_equals_the_serial_pass():
     doc.sentences[1200].words[-1].word = 5
     with pytest.raises(TypeError):
         hm.geometry(doc.sentences, 8)
+
+
+def test_lemma_key_pass_in_c_equals_the_dict_of_tuples():
+    """`lemma_keys` / `assign_lemmas` (Lemmatizer.process_bucketed's passes over every word) against the Python pass they
+    replace: distinct (word, upos, lang_id) in order of first appearance, words over 25 characters skipped and left
+    alone, equal strings that are different objects share a key, an empty sentence, non-str upos values."""
+    from cube_amd import host
+    hm = host.load()
+    _, enc, _ = cases.parser_model(cases.TINY)
+    rng = np.random.default_rng(11)
+    doc = synth.make_document(enc, rng.integers(1, 30, size=300), seed=8, ext_word_emb=(4,), max_word_len=9)
+    sents = doc.sentences
+    sents[5].words = []
+    tags = ["NOUN", "VERB", None, 3]
+    for si, s in enumerate(sents):
+        s.lang_id = si % 3
+        for wi, w in enumerate(s.words):
+            w.upos = tags[(si + wi) % 4]
+            w.lemma = "old"
+            if (si + wi) % 7 == 0:
+                w.word = "".join(["re", "peat"])        # equal text, a new object every time
+                w.upos = "".join(["NO", "UN"])
+    sents[9].words[0].word = "x" * 26
+    sents[10].words[-1].word = "y" * 25
+
+    keys, order, widx = {}, [], []
+    for s in sents:
+        for w in s.words:
+            if len(w.word) <= 25:
+                k = (w.word, w.upos, s.lang_id)
+                i = keys.setdefault(k, len(order))
+                if i == len(order):
+                    order.append(k)
+                widx.append(i)
+    k_word, k_upos, k_lang, lens, idx = hm.lemma_keys(sents, 25)
+    assert list(zip(k_word, k_upos, k_lang.tolist())) == order
+    assert lens.tolist() == [len(k[0]) for k in order] and idx.tolist() == widx and idx.dtype == np.int32
+    lemmas = ["L%d" % i for i in range(len(order))]
+    hm.assign_lemmas(sents, idx, lemmas, 25)
+    it = iter(widx)
+    for s in sents:
+        for w in s.words:
+            assert w.lemma == ("old" if len(w.word) > 25 else lemmas[next(it)])
+    with pytest.raises(ValueError):
+        hm.assign_lemmas(sents, idx[:-1].copy(), lemmas, 25)
+    with pytest.raises(ValueError):
+        hm.assign_lemmas(sents, idx, lemmas[:-1], 25)
+    sents[3].words[0].word = 7
+    with pytest.raises(TypeError):
+        hm.lemma_keys(sents, 25)
+    with pytest.raises(TypeError):
+        hm.assign_lemmas(sents, idx, lemmas, 25)
