@@ -58,7 +58,8 @@ enum {
   CUBE_EPI_BF16 = 1,       /* out0 bf16 = C                                                      */
   CUBE_EPI_BF16_TANH = 2,  /* out0 bf16 = tanh(C)                                                */
   CUBE_EPI_BF16_RELU = 3,  /* out0 bf16 = relu(C)                                                */
-  CUBE_EPI_GATE = 4        /* gated conv layer, see below                                        */
+  CUBE_EPI_GATE = 4,       /* gated conv layer, see below                                        */
+  CUBE_EPI_LSTM = 5        /* one LSTM cell step on the gate pre-activations, see below          */
 };
 /* Precision.  Every bf16 tensor may come as a pair of planes, x ~= hi + lo ("*_lo" pointers,
  * same shape and leading dimension as the hi plane).  With A_lo and W_lo given ("bf16x3")
@@ -82,6 +83,18 @@ enum {
  *   bias_tab[(row_group[r] * 32 + tapmask(r)) * N + n],   tapmask bit t = tap t is inside,
  * computed at load time (bias + sum over inside taps of W_lang[n, tap, :] . emb[group]), and the
  * GEMM runs over the remaining channels only.  bias_tab f32 [n_groups, 32, N]; row_group i32 [M]. */
+
+/* CUBE_EPI_LSTM (cube_gemm_bf16, one plain Linear problem: taps 1, no rowmap / groups / accumulate / batch): one step of
+ * a torch.nn.LSTM layer for M independent rows -- the decoder of the lemmatizer, lemmatizer.py:131,149 (self._decoder,
+ * two layers, one time step per call).  A[r, :] = [x_t | h_{t-1}] of row r, W = [W_ih | W_hh] with the 4*units gate
+ * rows (torch order i, f, g, o) packed so that the four pre-activations of a hidden unit meet in two neighbouring lanes:
+ *   column n = ub*64 + part*32 + 2*j + odd  holds gate (2*part + odd) of unit ub*16 + j      (j < 16, part, odd < 2),
+ * N >= ceil(units / 16) * 64 rounded up to a multiple of 128, bias = b_ih + b_hh in the same order, n_valid = units.
+ *   res  f32 [M, ld_res]: the cell state, read as c_{t-1} and overwritten with c_t = f*c + i*g
+ *   out0 bf16 [M, ldo0] (hi, optional lo): [r, col0 + u] = h_t = o * tanh(c_t)
+ *   out1 bf16 (optional): [r, col1 + u] = c_t (the attention query of lemmatizer.py:144 reads the cell state)
+ * out0 must not overlap the columns of A the launch reads (other workgroups may still be reading them): a caller that
+ * feeds h back keeps two activation buffers and alternates.  Same bits as CUBE_EPI_F32 followed by cube_lstm_cell.  */
 
 /* Ragged sequence groups (CUBE_EPI_GATE without res / rowmap).  The rows of A are n groups; group
  * g owns rows [row0_in, row0_in + n_rows) as sequences of seq_in rows (n_rows % seq_in == 0; its

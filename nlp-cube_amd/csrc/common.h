@@ -47,6 +47,15 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// One LSTM cell (torch.nn.LSTM, gate order i, f, g, o) from the four pre-activations and the old cell state; shared by
+// cube_lstm_cell and the CUBE_EPI_LSTM epilogue of the GEMM so that both give the same bits.  Explicit fma / mul: the two
+// callers must not be contracted differently.
+__device__ __forceinline__ void lstm_cell_update(float pi, float pf, float pg, float po, float c_old, float& c_new, float& h_new) {
+  const float gi = sigmoidf_(pi), gf = sigmoidf_(pf), gg = tanhf_(pg), go = sigmoidf_(po);
+  c_new = __fmaf_rn(gf, c_old, __fmul_rn(gi, gg));
+  h_new = __fmul_rn(go, tanhf_(c_new));
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember per
 // device (one process may drive several GPUs, from several host threads) what has been reserved for
 // a kernel.  The table is atomic: two threads that race on the first launch both set the attribute

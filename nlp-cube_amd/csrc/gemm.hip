@@ -718,6 +718,49 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
         }
       }
     }
+  } else if constexpr (EPI == CUBE_EPI_LSTM) {
+    // The four gate pre-activations of a hidden unit sit in two NEIGHBOURING lanes (cube_hip.h: columns packed
+    // [i f i f ..] in the wave's first 32-column block, [g o g o ..] in its second): the even lane holds i and g of
+    // its 16 rows, the odd lane f and o of the same rows.  They swap half of them -- the even lane takes rows r < 8,
+    // the odd lane rows r >= 8 -- and each then runs eight cell updates with everything in registers.
+    static_assert(TN == 2, "the LSTM epilogue pairs the two 32-column blocks of a wave");
+    const bool odd = l31 & 1;
+    const int unit = (wcol0 >> 6) * 16 + (l31 >> 1);
+    const bool unit_ok = unit < p.n_valid;
+    const float b0 = p.bias ? p.bias[wcol0 + l31] : 0.f, b1 = p.bias ? p.bias[wcol0 + 32 + l31] : 0.f;
+    float* __restrict__ cst = p.res;
+    uint16_t* __restrict__ h_hi = reinterpret_cast<uint16_t*>(p.out0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float mine0[8], mine1[8], oth0[8], oth1[8], cold[8];
+      int rows[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = odd ? k + 8 : k;
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        rows[k] = (row < p.M && unit_ok) ? row : -1;
+        cold[k] = rows[k] >= 0 ? cst[(size_t)row * p.ld_res + unit] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v0k = acc[i][0][k] + b0, v0k8 = acc[i][0][k + 8] + b0;
+        const float v1k = acc[i][1][k] + b1, v1k8 = acc[i][1][k + 8] + b1;
+        mine0[k] = odd ? v0k8 : v0k;   // what this lane keeps: its own gates of the rows it updates
+        mine1[k] = odd ? v1k8 : v1k;
+        oth0[k] = __shfl_xor(odd ? v0k : v0k8, 1, 64);   // ... and the neighbour's gates of those rows
+        oth1[k] = __shfl_xor(odd ? v1k : v1k8, 1, 64);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (rows[k] < 0) continue;
+        float cn, hn;
+        if (odd) lstm_cell_update(oth0[k], mine0[k], oth1[k], mine1[k], cold[k], cn, hn);
+        else lstm_cell_update(mine0[k], oth0[k], mine1[k], oth1[k], cold[k], cn, hn);
+        cst[(size_t)rows[k] * p.ld_res + unit] = cn;
+        store_bf16(h_hi, p.out0_lo, (size_t)rows[k] * p.ldo0 + p.col0 + unit, hn);
+        if (p.out1) store_bf16(p.out1, p.out1_lo, (size_t)rows[k] * p.ldo1 + p.col1 + unit, cn);
+      }
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -907,6 +950,26 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       if (a->epilogue == CUBE_EPI_BF16) rc = launch<CUBE_EPI_BF16>(p, cg, st);
       else if (a->epilogue == CUBE_EPI_BF16_TANH) rc = launch<CUBE_EPI_BF16_TANH>(p, cg, st);
       else rc = launch<CUBE_EPI_BF16_RELU>(p, cg, st);
+      break;
+    case CUBE_EPI_LSTM:
+      // n_valid = hidden units; N >= 4 * units rounded up to whole 64-column wave ranges (16 units each)
+      if (a->n_valid <= 0 || (a->n_valid + 15) / 16 * 64 > a->N) CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue: n_valid=%d units need N >= %d", fn, a->n_valid, (a->n_valid + 15) / 16 * 64);
+      if (a->taps != 1 || a->rowmap || a->groups || a->accumulate || p.batch > 1 || a->bias_tab)
+        CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue is for one plain Linear problem (taps 1, no rowmap / groups / accumulate / batch)", fn);
+      if (!a->res || a->ld_res < a->n_valid) CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue needs the cell state res[M, >= %d]", fn, a->n_valid);
+      if (!a->out0 || a->ldo0 < a->col0 + a->n_valid) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out0/ldo0", fn);
+      if (a->out1 && a->ldo1 < a->col1 + a->n_valid) CUBE_FAIL(CUBE_ERR_ARG, "%s: bad out1/ldo1", fn);
+      {  // h (and the bf16 copy of c) must not alias the columns of A that other workgroups still read
+        const char* a0 = (const char*)a->A;
+        const char* a1 = a0 + 2 * ((size_t)(a->M - 1) * a->lda + a->Kc);
+        const char* o0 = (const char*)a->out0 + 2 * (size_t)a->col0;
+        const char* o1 = o0 + 2 * ((size_t)(a->M - 1) * a->ldo0 + a->n_valid);
+        bool clash = o0 < a1 && a0 < o1 && a->lda == a->ldo0 &&
+                     ((o0 - a0) / 2 % a->lda) < (size_t)a->Kc;  // same row pitch: columns [col, col+units) against [0, Kc)
+        if (o0 < a1 && a0 < o1 && a->lda != a->ldo0) clash = true;
+        if (clash) CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue: out0 overlaps the columns of A this launch reads (use a second buffer)", fn);
+      }
+      rc = launch<CUBE_EPI_LSTM>(p, cg, st);
       break;
     case CUBE_EPI_GATE: {
       const int half = p.n_valid;  // valid channels; N/2 >= half when padded to the 128-column tile

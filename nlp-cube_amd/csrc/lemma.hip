@@ -173,10 +173,9 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
   if (idx >= B * H) return;
   const int b = idx / H, u = idx - b * H;
   const float* g = gates + (size_t)b * ld_g;
-  const float gi = sigmoidf_(g[u]), gf = sigmoidf_(g[H + u]), gg = tanhf_(g[2 * H + u]), go = sigmoidf_(g[3 * H + u]);
-  const float cn = gf * c[idx] + gi * gg;
+  float cn, hn;
+  lstm_cell_update(g[u], g[H + u], g[2 * H + u], g[3 * H + u], c[idx], cn, hn);
   c[idx] = cn;
-  const float hn = go * tanhf_(cn);
   uint16_t hi, lo;
   split_bf16(hn, hi, lo);
   h[(size_t)b * ld_h + col_h + u] = hi;

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
-EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE = 0, 1, 2, 3, 4
+EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE, EPI_LSTM = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 18  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t

@@ -13,6 +13,7 @@ A greedy step is 4 GEMMs (query taps, output heads, LSTM layers 0 and 1) + 3 row
 finished-word counter every `CHECK_EVERY` steps instead of every step (lemmatizer.py:139,161-163).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -115,6 +116,8 @@ class Word2TargetCollate:
 
 
 class Lemmatizer:
+    # LSTM cell updates in the epilogue of the gate GEMMs (False / CUBE_LEMMA_FUSED_CELL=0: EPI_F32 + cube_lstm_cell, same bits)
+    fused_cell = os.environ.get("CUBE_LEMMA_FUSED_CELL", "1") != "0"
     CHECK_EVERY = 8  # greedy steps between two looks at the finished-word counter
 
     def __init__(self, config, encodings, language_codes=None):
@@ -223,15 +226,22 @@ class Lemmatizer:
         B, S = ed["B"], ed["S"]
         limit = S * 20 if max_steps is None else max_steps
         D, ld_x = lay.D, lay.xd_w
-        xd = buf.get("xd", B, ld_x)
-        xd.hi[:B * ld_x].zero_()
-        if xd.lo is not None:
-            xd.lo[:B * ld_x].zero_()
+        fused = self.fused_cell
+        # fused: two decoder-state buffers taken in turn (X[cur] holds [ctx | prev char | h0] of the step that runs next and
+        # h1, c1 of the step before; a cell update in the GEMM epilogue may not write h into the columns other tiles read)
+        xd2 = buf.get("xd", 2 * B, ld_x)
+        xd2.hi[:2 * B * ld_x].zero_()
+        if xd2.lo is not None:
+            xd2.lo[:2 * B * ld_x].zero_()
+        X = [hip.Pair(xd2.hi[k * B * ld_x:(k + 1) * B * ld_x], None if xd2.lo is None else xd2.lo[k * B * ld_x:(k + 1) * B * ld_x])
+             for k in range(2 if fused else 1)]
+        xd = X[0]
         cs = buf.get("cells", 2 * B, D, torch.float32)
         cs[:2 * B * D].zero_()
         c0, c1 = cs[:B * D], cs[B * D:2 * B * D]
         l0, l1, qq, hh = pk["lstm0"], pk["lstm1"], pk["query"], pk["heads"]
-        gates = buf.get("gates", B, l0["N"], torch.float32)
+        f0, f1 = pk["lstm0f"], pk["lstm1f"]
+        gates = None if fused else buf.get("gates", B, l0["N"], torch.float32)
         ld_q = lay.q_w
         q = buf.get("q", B, ld_q, torch.float32)
         out = torch.zeros((2, B, max(limit, 1)), dtype=torch.int32, device=dev)
@@ -240,7 +250,15 @@ class Lemmatizer:
         self._live += [out, flags, logits]
         lo = hip.ptr
 
-        def lstm():
+        def lstm(cur):
+            """Both decoder layers for one time step (lemmatizer.py:131,149); the input row is X[cur]."""
+            if fused:   # the cell update is the epilogue of the gate GEMM (CUBE_EPI_LSTM): h0 -> X[1-cur], h1 / c1 -> X[cur]
+                xi, xo = X[cur], X[1 - cur]
+                hip.gemm(xi, ld_x, B, f0["K"], f0["W"], f0["N"], f0["bias"], hip.EPI_LSTM, out0=xo, ldo0=ld_x, col0=lay.xd_h0,
+                         n_valid=D, res=c0, ld_res=D, stream=st)
+                hip.gemm(xo, ld_x, B, f1["K"], f1["W"], f1["N"], f1["bias"], hip.EPI_LSTM, out0=xi, ldo0=ld_x, col0=lay.xd_h1,
+                         n_valid=D, res=c1, ld_res=D, out1=xi, ldo1=ld_x, col1=lay.xd_c1, a_col=lay.xd_h0, stream=st)
+                return
             hip.gemm(xd, ld_x, B, l0["K"], l0["W"], l0["N"], l0["bias"], hip.EPI_F32, out0=gates, ldo0=l0["N"],
                      n_valid=l0["N"], stream=st)
             hip.check(lib.cube_lstm_cell(gates.data_ptr(), l0["N"], D, c0.data_ptr(), B, xd.hi.data_ptr(), lo(xd.lo), ld_x,
@@ -258,23 +276,28 @@ class Lemmatizer:
         a.B, a.S = B, S
         a.char_emb, a.char_emb_lo = pk["char_emb"].hi.data_ptr(), lo(pk["char_emb"].lo)
         a.ld_emb, a.E = pk["char_emb"].hi.shape[1], packing.p8(lay.ce)
-        a.x, a.x_lo, a.ld_x, a.col_ctx, a.col_emb = xd.hi.data_ptr(), lo(xd.lo), ld_x, 0, lay.xd_emb
+        a.ld_x, a.col_ctx, a.col_emb = ld_x, 0, lay.xd_emb
         a.out_char, a.out_case, a.ld_out = out[0].data_ptr(), out[1].data_ptr(), out.shape[2]
         a.eol, a.done, a.n_done = self._eol, flags.data_ptr(), flags[B:].data_ptr()
 
         # start frame through the decoder with a zero state (lemmatizer.py:128-131)
-        self._gather(xd, ld_x, 0, lay.xd_h0, pk["start"], None, B)
-        lstm()
+        cur = 0
+        self._gather(X[cur], ld_x, 0, lay.xd_h0, pk["start"], None, B)
+        lstm(cur)
         steps = 0
         for s in range(limit + 1):
+            xs = X[cur]         # h1 / c1 of the step that has just run
             if s < limit:   # tap projections of the query (cell state c1) for this step's attention
-                hip.gemm(xd, ld_x, B, qq["K"], qq["W"], qq["N"], qq["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, n_valid=qq["N"],
+                hip.gemm(xs, ld_x, B, qq["K"], qq["W"], qq["N"], qq["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, n_valid=qq["N"],
                          a_col=lay.xd_c1, stream=st)
             if s > 0:       # output heads on h1 of the previous step
-                hip.gemm(xd, ld_x, B, hh["K"], hh["W"], hh["N"], hh["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, col0=lay.q_char,
+                hip.gemm(xs, ld_x, B, hh["K"], hh["W"], hh["N"], hh["bias"], hip.EPI_F32, out0=q, ldo0=ld_q, col0=lay.q_char,
                          n_valid=hh["N"], a_col=lay.xd_h1, stream=st)
             if keep_logits and s > 0:
                 logits[s - 1].copy_(q[:B * ld_q].view(B, ld_q)[:, lay.q_char:lay.q_char + lay.n_char + lay.n_case])
+            if fused:
+                cur = 1 - cur   # context and the chosen character's embedding go into the NEXT step's input row
+            a.x, a.x_lo = X[cur].hi.data_ptr(), lo(X[cur].lo)
             a.step, a.attend = s, int(s < limit)
             hip.check(lib.cube_lemma_attend(ctypes.byref(a), st), "cube_lemma_attend")
             steps = s
@@ -282,7 +305,7 @@ class Lemmatizer:
                 break
             if s > 0 and s % self.CHECK_EVERY == 0 and int(flags[B].item()) == B:
                 break
-            lstm()
+            lstm(cur)
         if defer:
             n_int = out.numel()
             ring = self.__dict__.setdefault("_pinned_ring", [])

@@ -588,6 +588,18 @@ class LemmaLayout:
         return perm
 
 
+def lstm_epilogue_rows(units):
+    """Packed gate row -> row of torch's [4*units] gate order (i, f, g, o), -1 = padding, for CUBE_EPI_LSTM:
+    column ub*64 + part*32 + 2*j + odd holds gate 2*part + odd of unit ub*16 + j (include/cube_hip.h)."""
+    nb = (units + 15) // 16
+    perm = -np.ones(nb * 64, dtype=np.int64)
+    for u in range(units):
+        ub, j = divmod(u, 16)
+        for gate in range(4):
+            perm[ub * 64 + (gate >> 1) * 32 + 2 * j + (gate & 1)] = gate * units + u
+    return perm
+
+
 def pack_lemmatizer(sd, cfg, n_chars):
     lay = LemmaLayout(cfg, n_chars)
     ce, ue, le, D, P, half = lay.ce, lay.ue, lay.le, lay.D, lay.P, lay.half
@@ -646,6 +658,17 @@ def pack_lemmatizer(sd, cfg, n_chars):
     b1 = torch.zeros(ng, dtype=torch.float32)
     b1[:4 * D] = sd["_decoder.bias_ih_l1"].float() + sd["_decoder.bias_hh_l1"].float()
     pk["lstm1"] = dict(W=_bf16(W1), bias=b1, K=2 * KD, N=ng)
+    # the same two layers with the gate rows in the order of CUBE_EPI_LSTM (include/cube_hip.h): the four pre-activations
+    # of a hidden unit in two neighbouring lanes of the GEMM's accumulator tile, so that the cell update runs in the epilogue
+    perm = lstm_epilogue_rows(D)
+    ngf = (len(perm) + 255) // 256 * 256
+    for name, Wf, bf in (("lstm0f", W0, b0), ("lstm1f", W1, b1)):
+        Wp, bp = _dense(ngf, Wf.shape[1]), torch.zeros(ngf, dtype=torch.float32)
+        ok = torch.from_numpy(perm >= 0)
+        srcr = torch.from_numpy(perm[perm >= 0])
+        Wp[:len(perm)][ok] = Wf[srcr]
+        bp[:len(perm)][ok] = bf[srcr]
+        pk[name] = dict(W=_bf16(Wp), bias=bp, K=Wf.shape[1], N=ngf)
     # start frame (lemmatizer.py:128-131) laid out as the [ctx | prev char] part of a decoder row
     sf = sd["_start_frame.weight"].float()[0]
     row = torch.zeros((1, lay.xd_h0), dtype=torch.float32)

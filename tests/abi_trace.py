@@ -89,8 +89,18 @@ class TraceLib:
         for nm, p in (("W", a.W), ("W_lo", a.W_lo)):
             self._need("gemm " + nm, p, 2 * ((nbat - 1) * a.stride_W + N * taps * Kc), 16)
         gate = a.epilogue == hip.EPI_GATE
+        cell = a.epilogue == hip.EPI_LSTM  # n_valid = hidden units; the bias covers every packed gate column
         nv = a.n_valid if a.n_valid > 0 else (N // 2 if gate else N)
-        self._need("gemm bias", a.bias, 4 * ((nbat - 1) * a.stride_bias + (N if gate else nv)), 4)
+        if cell:
+            assert taps == 1 and nbat == 1 and not a.rowmap and not a.groups and not a.accumulate and not a.bias_tab
+            assert 0 < nv and (nv + 15) // 16 * 64 <= N and a.res and a.out0
+            # h must not land in memory the launch reads as A (other tiles may still be reading it): the two are
+            # different buffers (the decoder alternates between two state buffers)
+            a_lo, a_hi = a.A, a.A + 2 * ((M - 1) * a.lda + Kc)
+            o_lo = a.out0 + 2 * a.col0
+            o_hi = o_lo + 2 * ((M - 1) * a.ldo0 + nv)
+            assert o_hi <= a_lo or a_hi <= o_lo, "LSTM epilogue writes h into the rows of A"
+        self._need("gemm bias", a.bias, 4 * ((nbat - 1) * a.stride_bias + (N if gate or cell else nv)), 4)
         out_rows, n_words = M, M
         if a.groups:
             cg = a.groups.contents
@@ -119,7 +129,7 @@ class TraceLib:
         assert a.ldo0 >= last_col + nv or not a.out0
         for nm, p in (("out0", a.out0), ("out0_lo", a.out0_lo)):
             self._need("gemm " + nm, p, esz * ((rows - 1) * a.ldo0 + last_col + nv), esz)
-        if gate:
+        if gate or cell:
             self._need("gemm res", a.res, 4 * ((M - 1) * a.ld_res + nv), 4)
             for nm, p, ld, c in (("out1", a.out1, a.ldo1, a.col1), ("out1_lo", a.out1_lo, a.ldo1, a.col1),
                                  ("out2", a.out2, a.ldo2, a.col2), ("out2_lo", a.out2_lo, a.ldo2, a.col2)):

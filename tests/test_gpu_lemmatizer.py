@@ -311,3 +311,74 @@ def test_merged_reference_batches_do_not_change_lemmas(dev):
     finally:
         m.max_steps = None
     assert [w.lemma for s in a.sentences for w in s.words] == [w.lemma for s in b.sentences for w in s.words]
+
+
+@pytest.mark.parametrize("units,M,K", [(300, 37, 384), (300, 1300, 640), (16, 5, 32), (200, 300, 96)])
+def test_lstm_epilogue_equals_gemm_then_cell(dev, units, M, K):
+    """CUBE_EPI_LSTM (the cell update of lemmatizer.py:131,149 in the epilogue of the gate GEMM, gate rows packed per
+    include/cube_hip.h) gives the same bits as CUBE_EPI_F32 followed by cube_lstm_cell: h, the bf16 copy of c, and c."""
+    from cube_amd import hip
+    from cube_amd.networks import packing
+    lib = hip.load()
+    g = torch.Generator().manual_seed(units * 1000 + M)
+    W = torch.randn((4 * units, K), generator=g) * 0.2
+    b = torch.randn(4 * units, generator=g) * 0.3
+    x = torch.randn((M, K), generator=g)
+    c_prev = torch.randn((M, units), generator=g)
+    ng = (4 * units + 255) // 256 * 256
+    Wd, bd = torch.zeros((ng, K)), torch.zeros(ng)
+    Wd[:4 * units], bd[:4 * units] = W, b
+    perm = packing.lstm_epilogue_rows(units)
+    ngf = (len(perm) + 255) // 256 * 256
+    Wf, bf = torch.zeros((ngf, K)), torch.zeros(ngf)
+    Wf[:len(perm)][torch.from_numpy(perm >= 0)] = W[torch.from_numpy(perm[perm >= 0])]
+    bf[:len(perm)][torch.from_numpy(perm >= 0)] = b[torch.from_numpy(perm[perm >= 0])]
+    up = lambda t: hip.Pair.split(t).to(dev)
+    A, Wd_p, Wf_p = up(x), up(Wd), up(Wf)
+    bd, bf = bd.to(dev), bf.to(dev)
+    ld_h = packing.p32(units) * 2
+    res = {}
+    for fused in (False, True):
+        c = c_prev.clone().to(dev).contiguous()
+        h = hip.Pair(torch.zeros((M, ld_h), dtype=torch.bfloat16, device=dev), torch.zeros((M, ld_h), dtype=torch.bfloat16, device=dev))
+        col_h, col_c = 0, packing.p32(units)
+        if fused:
+            hip.gemm(A, K, M, K, Wf_p, ngf, bf, hip.EPI_LSTM, out0=h, ldo0=ld_h, col0=col_h, n_valid=units, res=c, ld_res=units,
+                     out1=h, ldo1=ld_h, col1=col_c)
+        else:
+            gates = torch.zeros((M, ng), dtype=torch.float32, device=dev)
+            hip.gemm(A, K, M, K, Wd_p, ng, bd, hip.EPI_F32, out0=gates, ldo0=ng, n_valid=ng)
+            hip.check(lib.cube_lstm_cell(gates.data_ptr(), ng, units, c.data_ptr(), M, h.hi.data_ptr(), h.lo.data_ptr(), ld_h, col_h,
+                                         h.hi.data_ptr(), h.lo.data_ptr(), col_c, hip.stream_handle()), "cube_lstm_cell")
+        torch.cuda.synchronize()
+        res[fused] = (c.cpu(), h.hi.cpu(), h.lo.cpu())
+    bits = lambda t: t.view(torch.int16) if t.dtype == torch.bfloat16 else t.view(torch.int32)
+    for a_, b_ in zip(res[False], res[True]):
+        assert torch.equal(bits(a_), bits(b_))
+    # and the update itself against torch's formula (fp32 grade: the operands are hi/lo bf16 pairs)
+    gt = x.double() @ W.double().T + b.double()
+    i_, f_, g_, o_ = [gt[:, k * units:(k + 1) * units] for k in range(4)]
+    c_ref = torch.sigmoid(f_) * c_prev.double() + torch.sigmoid(i_) * torch.tanh(g_)
+    h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+    h_got = (res[True][1].float() + res[True][2].float())[:, :units].double()
+    assert float((res[True][0].double() - c_ref).abs().max()) < 1e-3 * float(c_ref.abs().max())
+    assert float((h_got - h_ref).abs().max()) < 1e-3
+    # an output that overlaps the columns of A is refused
+    with pytest.raises(hip.CubeHipError):
+        hip.gemm(A, K, M, K, Wf_p, ngf, bf, hip.EPI_LSTM, out0=A, ldo0=K, col0=0, n_valid=min(units, K), res=c, ld_res=units)
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_fused_cell_decoder_equals_separate_cell_kernel(dev, tag):
+    """Lemmatizer.forward with the cell updates in the GEMM epilogues (two decoder-state buffers taken in turn) == the
+    same with CUBE_EPI_F32 + cube_lstm_cell on one buffer: every logit of every step, bit for bit."""
+    m, cfg, enc, sd = _model(tag, dev)
+    X = _batch(enc, "ragged", 37)
+    try:
+        m.fused_cell = True
+        yc1, yk1 = m.forward(X)
+        m.fused_cell = False
+        yc0, yk0 = m.forward(X)
+    finally:
+        m.fused_cell = True
+    assert torch.equal(yc0, yc1) and torch.equal(yk0, yk1)

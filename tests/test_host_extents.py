@@ -128,11 +128,15 @@ def test_lemmatizer_host_extents(case, precision, monkeypatch):
     m, lib = abi_trace.dry_lemmatizer(cfg, enc, sd, precision, monkeypatch)
     ds = LemmaDataset(cases.lemma_document(enc, "ragged"), for_training=False)
     col = Word2TargetCollate(enc)
-    for n in (1, 5, len(ds)):
-        X = col.collate_fn([ds[i] for i in range(n)], targets=False)
-        oc, ok, steps, logits = m._decode(m._encode(X), max_steps=11, keep_logits=True)
-        assert oc.shape == (n, 11) and steps == 11 and logits.shape[0] == 11
-    kinds = {c[0] for c in lib.calls}
+    for fused in (True, False):   # cell updates in the GEMM epilogue (two state buffers) / cube_lstm_cell
+        m.fused_cell = fused
+        for n in (1, 5, len(ds)):
+            X = col.collate_fn([ds[i] for i in range(n)], targets=False)
+            oc, ok, steps, logits = m._decode(m._encode(X), max_steps=11, keep_logits=True)
+            assert oc.shape == (n, 11) and steps == 11 and logits.shape[0] == 11
+        kinds = {c[0] for c in lib.calls}
+        assert ("lstm_cell" in kinds) == (not fused)
+        assert any(c[0] == "gemm" and c[1] == abi_trace.hip.EPI_LSTM for c in lib.calls)
     assert {"gemm", "gather", "lemma_attend", "lstm_cell"} <= kinds
 
 
