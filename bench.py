@@ -370,7 +370,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if args.config == 3 else "weak", "vs_baseline": None,
         # the default precision = the mode tests/test_gpu_parity.py holds to north_star's 99.9 % on the two full-size batches
         "dtype": p.precision + ("+int8x2" if i8 else ""),
-        "precision": dict(mode=p.precision, char_int8=bool(p.char_int8), word_int8=bool(p.word_int8), lstm_int8=bool(p.lstm_int8),
+        "precision": dict(mode=p.precision, char_int8=bool(p.char_int8), word_int8=bool(p.word_int8), word0_int8=bool(p.word_int8 and p.word0_int8), lstm_int8=bool(p.lstm_int8),
                           what="bf16x3 = hi/lo bf16 planes, hi*hi + hi*lo + lo*hi on the matrix cores, fp32 accumulate; int8x2 = two "
                                "int8 slices (16-bit fixed point) for the gated convolutions of layers >= 1 and for h in the BiLSTM "
                                "recurrence (W_hh 14 bits), exact int32 accumulate"),

@@ -226,6 +226,15 @@ int cube_masked_mean_i8(const void* const* x_hi, const void* const* x_lo, const 
                         int ld_x, const int32_t* len, int N, int W, int C,
                         void* out, void* out_lo, int ld_out, const int32_t* word_rows, void* stream);
 
+/* bf16 hi (+ lo) rows -> int8x2 planes with one scale per COLUMN: q[r, c] = round(clamp(x[r, c] * inv_scale[c], -1, 1) *
+ * CUBE_I8_ONE) = 256*hi + lo.  Input of a cube_gemm_i8x2 layer whose activations are not gate outputs -- the first
+ * word-level gated convolution reads the concatenation [word emb | char vector | lang emb | ext] (parser.py:149-158,
+ * tagger.py:121-129): the packer takes 1 / inv_scale[c] = the largest magnitude the column's block can hold (the embedding
+ * table's maximum; 1 for tanh outputs; the parser's root row included) and folds it into the layer's weights.  cols, ld_x
+ * (bf16 elements) and ld_q (bytes) multiples of 8; inv_scale f32 [cols], 0 for padding columns; x_lo may be NULL.      */
+int cube_quant_i8x2(const void* x, const void* x_lo, int ld_x, int rows, int cols, const float* inv_scale, void* q, void* q_lo,
+                    int ld_q, void* stream);
+
 /* e = tanh(sum_j acc[r, j*part_stride + 0..P) / K)  (acc f32 [B*L, ld_acc], row r = b*L + i; j < parts, summed in
  * that order: parts = 1 when the GEMMs accumulated in place, parts = K after one batched launch of the K second layers);
  * bf16(e) -> dst_a[(b*(L+root) + i + root), col_a..+P) and dst_b[same row, col_b..+P);

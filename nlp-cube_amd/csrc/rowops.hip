@@ -15,7 +15,7 @@ void cube_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* cube_last_error(void) { return g_err; }
-extern "C" int cube_abi_version(void) { return 18; }
+extern "C" int cube_abi_version(void) { return 19; }
 
 namespace {
 
@@ -695,5 +695,57 @@ extern "C" int cube_split_f32(const float* x, size_t n, void* hi, void* lo, void
   hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, n4, (uint2*)hi,
                      (uint2*)lo);
   CUBE_CHECK_LAUNCH("cube_split_f32");
+  return CUBE_OK;
+}
+
+// ---- bf16 hi/lo rows -> int8x2 planes with one scale per column (input of a cube_gemm_i8x2 layer whose activations are not
+// gate outputs: the first word-level gated convolution reads [word emb | char vector | lang emb | ext], parser.py:149-158)
+__global__ __launch_bounds__(256) void quant_i8x2_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_lo, int ld_x,
+                                                         int rows, int cols8, const float* __restrict__ inv_scale,
+                                                         unsigned char* __restrict__ q, unsigned char* __restrict__ q_lo, int ld_q) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * cols8) return;
+  const int r = idx / cols8, c = (idx - r * cols8) * 8;
+  const uint4 h = *reinterpret_cast<const uint4*>(x + (size_t)r * ld_x + c);
+  uint4 l = {0u, 0u, 0u, 0u};
+  if (x_lo) l = *reinterpret_cast<const uint4*>(x_lo + (size_t)r * ld_x + c);
+  const float4 s0 = *reinterpret_cast<const float4*>(inv_scale + c), s1 = *reinterpret_cast<const float4*>(inv_scale + c + 4);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+  const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  uint32_t t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint32_t hb = (e & 1) ? (hw[e >> 1] & 0xffff0000u) : (hw[e >> 1] << 16);
+    const uint32_t lb = (e & 1) ? (lw[e >> 1] & 0xffff0000u) : (lw[e >> 1] << 16);
+    float v = (__uint_as_float(hb) + __uint_as_float(lb)) * sc[e];   // hi + lo is exact in fp32 (16 significant bits)
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    // q = round-to-nearest-even(v * CUBE_I8_ONE): the low 16 bits of this sum are q + 128 (gemm.hip, int8x2 gate epilogue)
+    t[e] = __float_as_uint(fmaf(v, (float)CUBE_I8_ONE, 12582912.0f + 128.0f));
+  }
+  static_assert(CUBE_I8_SHIFT == 8, "byte extraction written for 8 + 8 bits");
+  uint32_t dh[2], dl[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t p01 = __builtin_amdgcn_perm(t[4 * k + 1], t[4 * k], 0x05010400u), p23 = __builtin_amdgcn_perm(t[4 * k + 3], t[4 * k + 2], 0x05010400u);
+    dl[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+    dh[k] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+  }
+  *reinterpret_cast<uint2*>(q + (size_t)r * ld_q + c) = uint2{dh[0], dh[1]};
+  *reinterpret_cast<uint2*>(q_lo + (size_t)r * ld_q + c) = uint2{dl[0], dl[1]};
+}
+
+extern "C" int cube_quant_i8x2(const void* x, const void* x_lo, int ld_x, int rows, int cols, const float* inv_scale, void* q,
+                               void* q_lo, int ld_q, void* stream) {
+  CUBE_ENTRY();
+  if (rows <= 0 || cols <= 0) return CUBE_OK;
+  if (!x || !inv_scale || !q || !q_lo) CUBE_FAIL(CUBE_ERR_ARG, "cube_quant_i8x2: null pointer");
+  if (cols % 8 || ld_x < cols || ld_q < cols || ld_x % 8 || ld_q % 8) CUBE_FAIL(CUBE_ERR_ARG, "cube_quant_i8x2: cols=%d ld_x=%d ld_q=%d (multiples of 8)", cols, ld_x, ld_q);
+  if ((uintptr_t)x % 16 || (uintptr_t)x_lo % 16 || (uintptr_t)inv_scale % 16 || (uintptr_t)q % 8 || (uintptr_t)q_lo % 8)
+    CUBE_FAIL(CUBE_ERR_ALIGN, "cube_quant_i8x2: x / inv_scale 16-byte aligned, q 8-byte aligned");
+  if ((long long)rows * (cols / 8) > 0x7fffffffLL) CUBE_FAIL(CUBE_ERR_ARG, "cube_quant_i8x2: too large");
+  const int total = rows * (cols / 8);
+  hipLaunchKernelGGL(quant_i8x2_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                     (const uint16_t*)x_lo, ld_x, rows, cols / 8, inv_scale, (unsigned char*)q, (unsigned char*)q_lo, ld_q);
+  CUBE_CHECK_LAUNCH("cube_quant_i8x2");
   return CUBE_OK;
 }

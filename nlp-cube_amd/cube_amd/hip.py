@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcubehip.so")
 
 EPI_F32, EPI_BF16, EPI_BF16_TANH, EPI_BF16_RELU, EPI_GATE, EPI_LSTM = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 18  # include/cube_hip.h; a stale libcubehip.so is refused
+ABI_VERSION = 19  # include/cube_hip.h; a stale libcubehip.so is refused
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 
@@ -119,6 +119,7 @@ SIGNATURES = {
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_split_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "cube_quant_i8x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "cube_subword_pool": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p]),
     "cube_argmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

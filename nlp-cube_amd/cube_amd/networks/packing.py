@@ -69,7 +69,7 @@ def quant_row_error(w, wq):
     return float(((wq - w).norm(dim=1)[ok] / den[ok]).max())
 
 
-def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False):
+def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False, in_scale=None):
     """-> dict(W bf16 [N, taps*Kc], bias f32 [N], Kc, N, half).
     in_perm: for each column of the HIP activation buffer, the reference input channel (or -1).
     bcast = (reference channels, table [G, len(channels)]): input channels that carry the same
@@ -79,7 +79,9 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False)
     W[:, channels, t] @ table[g]  (m = the taps that fall inside the sequence at a position).
     `bias_tab_q` is the same from bf16-rounded weights and table (single-pass "bf16" contract).
     int8: also `W8` (Pair of int8 planes [N, taps*Kc], 64-channel chunks) and `w_scale` f32 [N] for
-    cube_gemm_i8x2: w[n, :] = (256*hi + lo) * max|w[n, :]| / I8_ONE (include/cube_hip.h)."""
+    cube_gemm_i8x2: w[n, :] = (256*hi + lo) * max|w[n, :]| / I8_ONE (include/cube_hip.h).
+    in_scale (f32 per buffer column, with int8): the layer's int8x2 input holds x[:, c] / in_scale[c] (cube_quant_i8x2), so the
+    fixed-point weights are those of W * in_scale; `W` (bf16) stays unscaled for the bf16x3 route."""
     w = sd[prefix + ".0.conv.weight"].float()  # [F, Cin, taps]
     b = sd[prefix + ".0.conv.bias"].float()
     s = sd[prefix + ".1.weight"].float() / torch.sqrt(sd[prefix + ".1.running_var"].float() + 1e-5)
@@ -106,18 +108,26 @@ def pack_gated_conv(sd, prefix, in_perm, double_first=0, bcast=None, int8=False)
     W[valid_n] = tmp
     bias[valid_n] = b[src_n]
     q8 = None
-    if int8 and Kc % 64 == 0:
+    if int8 and (Kc % 64 == 0 or in_scale is not None):
         from cube_amd.hip import I8_ONE, I8_SHIFT, Pair
-        wmax = W.abs().amax(dim=(1, 2)).double().clamp(min=1e-30)
-        q = torch.round(W.double() / wmax[:, None, None] * I8_ONE).to(torch.int32)
+        Kc8 = (Kc + 63) // 64 * 64   # the int8x2 tile reads 64-channel chunks: a quantised input buffer is padded to that
+        Ws = W
+        if in_scale is not None:
+            scv = torch.ones(Kc, dtype=torch.float32)
+            scv[:len(in_scale)] = torch.as_tensor(np.asarray(in_scale), dtype=torch.float32)
+            Ws = W * scv[None, None, :]
+        wmax = Ws.abs().amax(dim=(1, 2)).double().clamp(min=1e-30)
+        q = torch.round(Ws.double() / wmax[:, None, None] * I8_ONE).to(torch.int32)
         hi = (q + (1 << (I8_SHIFT - 1))) >> I8_SHIFT  # arithmetic shift = floor: hi in [-127, 127], lo in [-128, 127]
         lo = q - (hi << I8_SHIFT)
         assert int(hi.abs().max()) <= 127 and int(lo.min()) >= -128 and int(lo.max()) <= 127
 
         def chunks(t):
-            return t.view(N, taps, Kc // 64, 64).permute(0, 2, 1, 3).reshape(N, taps * Kc).to(torch.int8).contiguous()
-        q8 = dict(W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * float(1 << I8_SHIFT) / (I8_ONE * I8_ONE)).float().contiguous())
-        q_err = quant_row_error(W, q.double() * wmax[:, None, None] / I8_ONE)
+            if Kc8 != Kc:
+                t = torch.cat([t, torch.zeros((N, taps, Kc8 - Kc), dtype=t.dtype)], dim=2)
+            return t.view(N, taps, Kc8 // 64, 64).permute(0, 2, 1, 3).reshape(N, taps * Kc8).to(torch.int8).contiguous()
+        q8 = dict(Kc8=Kc8, W8=Pair(chunks(hi), chunks(lo)), w_scale=(wmax * float(1 << I8_SHIFT) / (I8_ONE * I8_ONE)).float().contiguous())
+        q_err = quant_row_error(Ws, q.double() * wmax[:, None, None] / I8_ONE)
         if q_err > I8_CONV_WEIGHT_ERR:  # outlier weights: this layer's stack stays in bf16x3
             q8 = dict(int8_refused=q_err)
     # K order of cube_gemm_bf16: 32-channel chunk outer, tap inner
@@ -259,6 +269,25 @@ def pack_wordgram(sd, prefix, n_layers, char_emb, case_emb, lang, half):
     return pk
 
 
+def xw0_block_scales(sd, lay):
+    """One quantisation scale per column of XW0 ([word | char | lang | ext], `Layout`): the largest |value| the column's
+    block can hold.  The parser's learned root row (`_r_emb`, parser.py:153-156) is written into XW0 in buffer order."""
+    blocks = [(0, lay.word_emb, float(sd["_word_emb.weight"].float().abs().max())),
+              (lay.xw0_char, lay.xw0_char + lay.char_half, 1.0),
+              (lay.xw0_lang, lay.xw0_lang + lay.lang, float(sd["_lang_emb.weight"].float().abs().max())),
+              (lay.xw0_ext, lay.xw0_ext + lay.P, 1.0)]
+    root = None
+    if "_r_emb.weight" in sd:
+        root = sd["_r_emb.weight"].float()[0][torch.from_numpy(lay.xw0_perm())].abs()
+    sc = np.ones(lay.xw0_n, dtype=np.float32)
+    for c0, c1, m in blocks:
+        if root is not None:
+            m = max(m, float(root[c0:c1].max()))
+        # bf16 hi + lo of a value can exceed it by an ulp of the lo plane; a power-of-two margin keeps 1/scale exact enough
+        sc[c0:c1] = max(m, 1e-30) * (1.0 + 2.0 ** -12)
+    return sc
+
+
 def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
     """Pieces shared by Parser and Tagger: WordGram, ext MLPs, word-level conv stack, aux heads."""
     pk = pack_wordgram(sd, "_word_net", cfg.char_layers, lay.char_emb, lay.case_emb, lay.lang, lay.char_half)
@@ -285,7 +314,16 @@ def pack_front(sd, cfg, enc_sizes, ext_dims, lay):
     for l in range(cfg.cnn_layers):
         # layer 0 keeps its lang channels in the GEMM (the parser's root row carries its own, parser.py:153-156)
         if l == 0:
-            pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, perm0))
+            # int8x2 for layer 0 as well: its input [word | char | lang | ext] is quantised with one scale per block -- the
+            # largest magnitude the block can hold: the embedding tables' maxima, 1 for the two tanh outputs, and the root
+            # row's own values where it has one (parser.py:153-156)
+            sc = xw0_block_scales(sd, lay)
+            cv = pack_gated_conv(sd, "_convs.%d" % l, perm0, int8=True, in_scale=sc)
+            if "W8" in cv:
+                inv = np.zeros(cv["Kc"], dtype=np.float32)   # padding columns: 0
+                inv[:len(sc)] = 1.0 / sc
+                cv["in_inv_scale"] = torch.from_numpy(inv)
+            pk["word_convs"].append(cv)
         else:
             pk["word_convs"].append(pack_gated_conv(sd, "_convs.%d" % l, np.arange(lay.word_half),
                                                     bcast=(lay.word_half + np.arange(lay.lang), lang_tab), int8=True))

@@ -100,6 +100,13 @@ class _HipNet:
         # word-level gated convolutions of layers >= 1 in the same int8x2 fixed point as the character CNN (their inputs
         # are gate outputs; the residual stream stays fp32).  False / CUBE_WORD_I8=0: bf16x3.
         self.word_int8 = os.environ.get("CUBE_WORD_I8", "1") != "0"
+        # ... and layer 0, whose input is the concatenation [word | char | lang | ext], after one pass that turns it into
+        # 16-bit fixed point with a scale per column block (cube_quant_i8x2).  Needs word_int8.  OFF by default: +1.7 %
+        # sentences/s at config 1 (187.5k -> 190.8k in an A/B on one box), but embeddings in fixed point over their full
+        # range are ~10x noisier than bf16x3 (UPOS logits 4e-5 -> 9e-5 relative, arc scores 2.7e-5 -> 3.6e-5) and config 0
+        # then differs from the reference's text in 21 of 1000 sentences where the parity suite allows 20 (14 lines with
+        # the default): decisions come first.  CUBE_WORD0_I8=1 / word0_int8 = True: on.
+        self.word0_int8 = os.environ.get("CUBE_WORD0_I8", "0") != "0"
         self._timing = None
         self._streams = None
         self._layouts = {}
@@ -597,16 +604,26 @@ class _HipNet:
             xwa, xwb = buf.get("xwa", BT, lay.xw_w), buf.get("xwb", BT, lay.xw_w)
         resw = buf.get("resw", BT, wh, torch.float32)
         src, src_ld = xw0, lay.xw0_w
+        # layer 0 in int8x2 as well: XW0 (embeddings, tanh outputs, the root row) -> 16-bit fixed point with one scale per
+        # column block (packing.xw0_block_scales, folded into the layer's fixed-point weights)
+        cv0 = pk["word_convs"][0]
+        w8_0 = w8 and self.word0_int8 and "W8" in cv0 and "in_inv_scale" in cv0 and cv0["Kc"] == lay.xw0_w
+        if w8_0:   # rows of Kc8 bytes per plane (64-channel chunks); the columns past xw0_w are never written and stay zero
+            k8 = cv0["Kc8"]
+            xw0q = buf.get("xw0q", BT, k8 // 2)
+            hip.check(lib.cube_quant_i8x2(xw0.hi.data_ptr(), lo(xw0.lo), lay.xw0_w, BT, lay.xw0_w, cv0["in_inv_scale"].data_ptr(),
+                                          xw0q.hi.data_ptr(), xw0q.lo.data_ptr(), k8, st), "cube_quant_i8x2")
+            src, src_ld = xw0q, k8
         for l, cv in enumerate(pk["word_convs"]):
             last = l == nword - 1
             dst = None if last else (xwa if l % 2 == 0 else xwb)
             aux_here = tap is not None and (l + 1 == cfg.aux_softmax_location)
             o1, o2 = (tap if aux_here else None), (final if last else None)
-            if w8 and l > 0:
-                hip.gemm(src, src_ld, BT, cv["Kc"], cv["W8"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
-                         col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh, res_mode=1,
-                         out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0, bias_tab=cv["bias_tab"],
-                         row_group=bt["lang_rows"], stream=st, w_scale=cv["w_scale"])
+            if w8 and (l > 0 or w8_0):
+                hip.gemm(src, src_ld, BT, cv["Kc8"], cv["W8"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,
+                         col0=0, taps=cv["taps"], seq_len=T, n_valid=cv["half"], res=resw, ld_res=wh, res_mode=0 if l == 0 else 1,
+                         out1=o1, ldo1=tap_w, col1=0, out2=o2, ldo2=final_w, col2=0, bias_tab=cv.get("bias_tab"),
+                         row_group=bt["lang_rows"] if "bias_tab" in cv else None, stream=st, w_scale=cv["w_scale"])
                 src, src_ld = dst, lay.xw_w
                 continue
             hip.gemm(src, src_ld, BT, cv["Kc"], cv["W"], cv["N"], cv["bias"], hip.EPI_GATE, out0=dst, ldo0=lay.xw_w,

@@ -308,6 +308,17 @@ class TraceLib:
     def cube_init(self):
         return 0
 
+    def cube_quant_i8x2(self, x, x_lo, ld_x, rows, cols, inv_scale, q, q_lo, ld_q, stream):
+        self.calls.append(("quant_i8x2", rows, cols))
+        assert cols % 8 == 0 and ld_x % 8 == 0 and ld_q % 8 == 0 and cols <= ld_x and cols <= ld_q and q and q_lo
+        self._need("quant_i8x2 x", x, 2 * ((rows - 1) * ld_x + cols), 16)
+        if x_lo:
+            self._need("quant_i8x2 x_lo", x_lo, 2 * ((rows - 1) * ld_x + cols), 16)
+        self._need("quant_i8x2 inv_scale", inv_scale, 4 * cols, 16)
+        self._need("quant_i8x2 q", q, (rows - 1) * ld_q + cols, 8)
+        self._need("quant_i8x2 q_lo", q_lo, (rows - 1) * ld_q + cols, 8)
+        return 0
+
     def cube_split_f32(self, x, n, hi, lo, stream):
         # x / hi / lo are allocated with exactly n elements by the caller (`_upload`) in the same statement, and
         # freed in stream order: only the contract on n and the alignments can be wrong

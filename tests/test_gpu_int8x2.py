@@ -186,21 +186,52 @@ def test_word_level_int8x2_layers_match_float64(dev):
     np.testing.assert_allclose(got1.numpy(), g1.numpy(), rtol=0, atol=1.5e-4)
 
 
+def test_quant_i8x2_is_round_to_nearest_of_the_scaled_value(dev):
+    """cube_quant_i8x2 against NumPy: q = rint(clip((hi + lo) * inv_scale, -1, 1) * I8_ONE) = 256*hi + lo, bit for bit,
+    padding columns (inv_scale 0) zero, values past the scale clamped."""
+    from cube_amd import hip
+    g = torch.Generator().manual_seed(11)
+    rows, cols, ld_x, ld_q = 77, 96, 104, 112
+    x = torch.randn((rows, ld_x), generator=g) * 1.5
+    x[3, 5], x[4, 6] = 9.0, -9.0
+    pair = hip.Pair.split(x)
+    inv = (1.0 / (torch.rand(cols, generator=g) * 3 + 0.5)).float()
+    inv[80:] = 0.0
+    q = hip.Pair(torch.full((rows, ld_q), 7, dtype=torch.int8, device=dev), torch.full((rows, ld_q), 7, dtype=torch.int8, device=dev))
+    pd, invd = pair.to(dev), inv.to(dev)
+    hip.check(hip.load().cube_quant_i8x2(pd.hi.data_ptr(), pd.lo.data_ptr(), ld_x, rows, cols, invd.data_ptr(), q.hi.data_ptr(),
+                                         q.lo.data_ptr(), ld_q, hip.stream_handle()), "cube_quant_i8x2")
+    torch.cuda.synchronize()
+    v = (pair.hi.float() + pair.lo.float())[:, :cols] * inv[None, :]          # fp32, as the kernel
+    want = np.rint(np.clip(v.numpy(), -1.0, 1.0).astype(np.float32) * np.float32(hip.I8_ONE) ).astype(np.int64)
+    # the kernel rounds v * I8_ONE inside ONE fma (no intermediate rounding of the product): allow the half-way cases
+    exact = np.clip(v.double().numpy(), -1, 1) * hip.I8_ONE
+    got = q.hi.cpu().numpy().astype(np.int64)[:, :cols] * (1 << hip.I8_SHIFT) + q.lo.cpu().numpy().astype(np.int64)[:, :cols]
+    assert np.abs(got - exact).max() <= 0.5 + 1e-6 and (np.abs(got - want) <= 1).all()
+    assert (got[:, 80:] == 0).all() and got[3, 5] == hip.I8_ONE and got[4, 6] == -hip.I8_ONE
+    hi8 = q.hi.cpu().numpy()[:, :cols].astype(np.int64)
+    assert np.abs(hi8).max() <= 127
+    assert (q.hi.cpu()[:, cols:] == 7).all() and (q.lo.cpu()[:, cols:] == 7).all()   # nothing past `cols` is written
+
+
 _CASES = [(cases.FULL, "full_8x32", "g3_forward_full.npz"), (cases.FULL, "full_2x128", "g3_forward_full.npz"),
           (cases.FULL, "ragged", "g3_forward_full.npz")]
 
 
-@pytest.mark.parametrize("i8", [True, False])
+@pytest.mark.parametrize("i8", [True, False, "word0"])
 @pytest.mark.parametrize("case,doc_key,fixture", _CASES)
 def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixture, i8):
     """`Parser.char_int8` on (the default) and off (bf16x3 in the character CNN too) against the
-    reference's own outputs, to the same bar."""
+    reference's own outputs, to the same bar; "word0": the opt-in int8x2 route of the FIRST word-level gated
+    convolution as well (cube_quant_i8x2 + cube_gemm_i8x2 with the block scales folded into its weights)."""
     from cube_amd.networks.parser import Parser
     from cube_amd.networks.utils import MorphoCollate
     from tests.test_gpu_parity import REL_TOL, _margin_ok, _rel
     cfg, enc, sd = cases.parser_model(case)
     p = Parser(cfg, enc, ext_word_emb=list(case["ext"]))
+    word0, i8 = i8 == "word0", bool(i8)
     p.char_int8 = i8
+    p.word0_int8 = word0
     p.load_state_dict(sd)
     p.to(dev)
     doc = cases.document(case, enc, doc_key)
@@ -209,6 +240,7 @@ def test_parser_char_int8_matches_reference(dev, golden_dir, case, doc_key, fixt
     r = p.decode_batch(X)
     torch.cuda.synchronize()
     assert ("xc_q1" in p._buf._b) == i8 and ("xc_g1" in p._buf._b) == (not i8), "wrong character-CNN path ran"
+    assert ("xw0q" in p._buf._b) == word0, "wrong route of the first word-level convolution ran"
     g = np.load(os.path.join(golden_dir, fixture))
     sl = r["bt"]["lens"].cpu().numpy()
     arc, ref_arc = r["arc_logits"].cpu().numpy(), g["%s/arc_logits" % doc_key]
