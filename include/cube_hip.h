@@ -371,6 +371,35 @@ int cube_lemma_attend(const cube_lemma_attend_args* args, void* stream);
 int cube_lstm_cell(const float* gates, int ld_g, int H, float* c, int B, void* h, void* h_lo, int ld_h, int col_h,
                    void* c16, void* c16_lo, int col_c, void* stream);
 
+/* ---- packed weights from a file: for hosts that cannot run the Python packer --------------------------------------
+ * The weight operands of every entry point above are LAYOUTS (BatchNorm folded in, gate-column order, chunked K, int8x2
+ * slices + scales, bias tables, LSTM gate-row orders, W_hh in fragment order) that cube_amd/networks/packing.py builds
+ * from a reference state_dict (the reference keeps nn.Module parameters, parser.py:23-95; there is no counterpart of a
+ * packed file in it).  `Parser.save_packed(path)` / `packing.save_packed` write them once, offline; these host-only calls
+ * map such a file and hand out every tensor by name -- e.g. "word_convs.1.W8.hi", "word_convs.1.w_scale",
+ * "char_convs.2.bias_tab" -- with its type and shape, and the integers that go into the argument structs -- "word_convs.1.Kc",
+ * "word_convs.1.N", "layout.xw0_w" ... (names: the keys of the packer's dict joined by dots, list indices as numbers,
+ * `hi` / `lo` for the planes of a bf16 or int8x2 pair, `layout.*` for the column offsets of the activation buffers).
+ * The host copies `data` (valid until cube_packfile_close, 256-byte aligned in the file) to device memory it owns.
+ * cube_packfile_open allocates the handle (the only allocation of this library that outlives a call);
+ * cube_packfile_close frees it.  No GPU is touched.                                                                    */
+enum { CUBE_PACK_F32 = 0, CUBE_PACK_BF16 = 1, CUBE_PACK_I8 = 2, CUBE_PACK_I32 = 3, CUBE_PACK_I64 = 4 };
+#define CUBE_PACK_MAX_DIMS 4
+typedef struct cube_pack_entry {
+  const char* name;      /* owned by the handle */
+  int dtype; int ndim;   /* CUBE_PACK_*; ndim 0 = scalar */
+  int64_t dims[CUBE_PACK_MAX_DIMS];
+  const void* data;      /* host pointer into the mapped file */
+  uint64_t nbytes;
+} cube_pack_entry;
+typedef struct cube_packfile cube_packfile;
+int cube_packfile_open(const char* path, cube_packfile** out);
+int cube_packfile_count(const cube_packfile* f);
+int cube_packfile_entry(const cube_packfile* f, int i, cube_pack_entry* out);
+int cube_packfile_find(const cube_packfile* f, const char* name, cube_pack_entry* out);
+int cube_packfile_int(const cube_packfile* f, const char* name, long long* value);
+void cube_packfile_close(cube_packfile* f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,12 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class PackEntry(ctypes.Structure):
+    """cube_pack_entry (include/cube_hip.h): one tensor or integer scalar of a packed-weights file."""
+    _fields_ = [("name", ctypes.c_char_p), ("dtype", c_int), ("ndim", c_int), ("dims", ctypes.c_int64 * 4),
+                ("data", c_void_p), ("nbytes", ctypes.c_uint64)]
+
+
 class LemmaAttendArgs(ctypes.Structure):
     """cube_lemma_attend_args (include/cube_hip.h)."""
     _fields_ = [
@@ -119,6 +125,12 @@ SIGNATURES = {
     "cube_ext_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cube_split_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "cube_packfile_open": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_void_p)]),
+    "cube_packfile_count": (c_int, [c_void_p]),
+    "cube_packfile_entry": (c_int, [c_void_p, c_int, ctypes.POINTER(PackEntry)]),
+    "cube_packfile_find": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(PackEntry)]),
+    "cube_packfile_int": (c_int, [c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]),
+    "cube_packfile_close": (None, [c_void_p]),
     "cube_quant_i8x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "cube_subword_pool": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p]),

@@ -150,6 +150,12 @@ class Lemmatizer:
         self.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True)["state_dict"])
         self.to(device)
 
+    def save_packed(self, path):
+        """Packed weights as a file for hosts that read them through cube_packfile_* (see `Parser.save_packed`)."""
+        if self._pk_cpu is None:
+            raise ValueError("load weights first (load / load_state_dict)")
+        return packing.save_packed(self._pk_cpu, path, self._lay)
+
     def to(self, device):
         device = torch.device(device)
         self._device = device

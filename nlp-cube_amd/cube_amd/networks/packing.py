@@ -554,6 +554,75 @@ def to_device(obj, device, with_lo=True):
 
 
 # ------------------------------------------------------------------------------------------
+# packed weights as a file, for hosts that cannot run this packer (include/cube_hip.h: cube_packfile_*)
+# ------------------------------------------------------------------------------------------
+PACK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int8: 2, torch.int32: 3, torch.int64: 4}
+
+
+def flatten_packed(pk, layout=None):
+    """The packer's nested dict -> [(name, tensor | int)]: keys joined by dots, list indices as numbers, `hi` / `lo` for
+    the planes of a Pair, `layout.<attr>` for the integer attributes of the layout object.  Floats, strings, None and
+    other Python-side bookkeeping are left out (a non-Python host has no use for them)."""
+    from cube_amd.hip import Pair
+    out = []
+
+    def walk(prefix, v):
+        if isinstance(v, Pair):
+            walk(prefix + ".hi", v.hi)
+            if v.lo is not None:
+                walk(prefix + ".lo", v.lo)
+        elif isinstance(v, torch.Tensor):
+            if v.dtype in PACK_DTYPES and v.dim() <= 4:
+                out.append((prefix, v.detach().cpu().contiguous()))
+        elif isinstance(v, bool):
+            out.append((prefix, int(v)))
+        elif isinstance(v, (int, np.integer)):
+            out.append((prefix, int(v)))
+        elif isinstance(v, dict):
+            for k in v:
+                walk(prefix + "." + str(k) if prefix else str(k), v[k])
+        elif isinstance(v, (list, tuple)):
+            for i, x in enumerate(v):
+                walk(prefix + "." + str(i) if prefix else str(i), x)
+
+    walk("", pk)
+    if layout is not None:
+        for k, v in sorted(vars(layout).items()):
+            if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
+                out.append(("layout." + k, int(v)))
+    return out
+
+
+def save_packed(pk, path, layout=None):
+    """Write the packed weights (host copy, both planes of every pair) to `path` in the format that cube_packfile_open
+    reads (nlp-cube_amd/csrc/packfile.hip).  -> number of entries."""
+    import struct
+    items = flatten_packed(pk, layout)
+    table, blobs, off = [], [], 0
+    for name, v in items:
+        nb = name.encode("utf-8")
+        if isinstance(v, int):
+            raw, code, dims = struct.pack("<q", v), 4, ()
+        else:
+            code, dims = PACK_DTYPES[v.dtype], tuple(v.shape)
+            raw = (v.view(torch.int16) if v.dtype == torch.bfloat16 else v).numpy().tobytes()
+        table.append(struct.pack("<H", len(nb)) + nb + struct.pack("<BB", code, len(dims)) +
+                     b"".join(struct.pack("<q", d) for d in dims) + struct.pack("<QQ", off, len(raw)))
+        blobs.append((off, raw))
+        off = (off + len(raw) + 255) // 256 * 256
+    tab = b"".join(table)
+    data_off = (32 + len(tab) + 255) // 256 * 256
+    with open(path, "wb") as f:
+        f.write(b"CUBEPACK" + struct.pack("<IIQQ", 1, len(items), len(tab), data_off))
+        f.write(tab)
+        for o, raw in blobs:
+            f.seek(data_off + o)
+            f.write(raw)
+        f.truncate(data_off + off if off else data_off)
+    return len(items)
+
+
+# ------------------------------------------------------------------------------------------
 # lemmatizer (reference: cube/networks/lemmatizer.py:24-69)
 # ------------------------------------------------------------------------------------------
 def p8(x):

@@ -152,6 +152,13 @@ class _HipNet:
             self._buf.streams = self._streams or ()
         return self
 
+    def save_packed(self, path):
+        """The packed weights of this model (after `load` / `load_state_dict`) as a file that a host in another language
+        reads through cube_packfile_* (include/cube_hip.h) instead of running the Python packer.  -> number of entries."""
+        if self._pk_cpu is None:
+            raise ValueError("load weights first (load / load_state_dict)")
+        return packing.save_packed(self._pk_cpu, path, self._lay)
+
     def _require_gpu(self):
         if self._pk is None or self._device.type != "cuda":
             raise hip.CubeHipError("cube_amd %s runs only on an MI355X: load weights and call .to('cuda:N') "
