@@ -383,8 +383,8 @@ int cube_lstm_cell(const float* gates, int ld_g, int H, float* c, int B, void* h
  * The host copies `data` (valid until cube_packfile_close, 256-byte aligned in the file) to device memory it owns.
  * cube_packfile_open allocates the handle (the only allocation of this library that outlives a call);
  * cube_packfile_close frees it.  No GPU is touched.                                                                    */
-enum { CUBE_PACK_F32 = 0, CUBE_PACK_BF16 = 1, CUBE_PACK_I8 = 2, CUBE_PACK_I32 = 3, CUBE_PACK_I64 = 4 };
-#define CUBE_PACK_MAX_DIMS 4
+enum { CUBE_PACK_F32 = 0, CUBE_PACK_BF16 = 1, CUBE_PACK_I8 = 2, CUBE_PACK_I32 = 3, CUBE_PACK_I64 = 4, CUBE_PACK_U8 = 5 };
+#define CUBE_PACK_MAX_DIMS 8
 typedef struct cube_pack_entry {
   const char* name;      /* owned by the handle */
   int dtype; int ndim;   /* CUBE_PACK_*; ndim 0 = scalar */

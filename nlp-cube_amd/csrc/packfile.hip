@@ -33,7 +33,7 @@ struct cube_packfile {
 
 namespace {
 
-const int ELEM_BYTES[] = {4, 2, 1, 4, 8};  // f32, bf16, i8, i32, i64
+const int ELEM_BYTES[] = {4, 2, 1, 4, 8, 1};  // f32, bf16, i8, i32, i64, u8
 
 struct Cursor {
   const unsigned char* p;
@@ -91,7 +91,7 @@ extern "C" int cube_packfile_open(const char* path, cube_packfile** out) {
     memset(&e, 0, sizeof(e));
     e.dtype = c.get<uint8_t>();
     e.ndim = c.get<uint8_t>();
-    if (!c.ok || e.dtype > CUBE_PACK_I64 || e.ndim > CUBE_PACK_MAX_DIMS) return fail("bad entry type / rank");
+    if (!c.ok || e.dtype > CUBE_PACK_U8 || e.ndim > CUBE_PACK_MAX_DIMS) return fail("bad entry type / rank");
     uint64_t count = 1;
     for (int d = 0; d < e.ndim; ++d) {
       e.dims[d] = c.get<int64_t>();

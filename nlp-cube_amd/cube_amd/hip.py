@@ -58,7 +58,7 @@ class GemmArgs(ctypes.Structure):
 
 class PackEntry(ctypes.Structure):
     """cube_pack_entry (include/cube_hip.h): one tensor or integer scalar of a packed-weights file."""
-    _fields_ = [("name", ctypes.c_char_p), ("dtype", c_int), ("ndim", c_int), ("dims", ctypes.c_int64 * 4),
+    _fields_ = [("name", ctypes.c_char_p), ("dtype", c_int), ("ndim", c_int), ("dims", ctypes.c_int64 * 8),
                 ("data", c_void_p), ("nbytes", ctypes.c_uint64)]
 
 

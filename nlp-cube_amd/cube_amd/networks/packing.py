@@ -556,7 +556,7 @@ def to_device(obj, device, with_lo=True):
 # ------------------------------------------------------------------------------------------
 # packed weights as a file, for hosts that cannot run this packer (include/cube_hip.h: cube_packfile_*)
 # ------------------------------------------------------------------------------------------
-PACK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int8: 2, torch.int32: 3, torch.int64: 4}
+PACK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int8: 2, torch.int32: 3, torch.int64: 4, torch.uint8: 5}
 
 
 def flatten_packed(pk, layout=None):
@@ -572,8 +572,10 @@ def flatten_packed(pk, layout=None):
             if v.lo is not None:
                 walk(prefix + ".lo", v.lo)
         elif isinstance(v, torch.Tensor):
-            if v.dtype in PACK_DTYPES and v.dim() <= 4:
-                out.append((prefix, v.detach().cpu().contiguous()))
+            if v.dtype not in PACK_DTYPES or v.dim() > 8:   # never drop an operand silently
+                raise TypeError("save_packed: %s has type %s / %d dimensions, which the file format does not hold"
+                                % (prefix, v.dtype, v.dim()))
+            out.append((prefix, v.detach().cpu().contiguous()))
         elif isinstance(v, bool):
             out.append((prefix, int(v)))
         elif isinstance(v, (int, np.integer)):
