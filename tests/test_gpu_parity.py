@@ -314,6 +314,47 @@ def test_mst_long_sentences_match_oracle(dev):
                   "cube_mst_decode")
 
 
+def _mst_sweep_batches(n_batches=24, B=48, seed=123):
+    """Random batches built to make the decoder contract: symmetric affinities (i and j prefer each other: 2-cycles
+    everywhere), block structure (cycles inside blocks, weak links between them), plain softmaxes at three temperatures,
+    ragged lengths from 1 word up."""
+    rng = np.random.default_rng(seed)
+    for k in range(n_batches):
+        L = int(rng.integers(2, 41))
+        lens = rng.integers(1, L + 1, size=B).astype(np.int64)
+        lens[0] = L
+        kind = k % 4
+        logits = rng.standard_normal((B, L, L + 1)) * (0.5, 2.0, 6.0)[k % 3]
+        if kind == 1:      # mutual preference between word pairs
+            a = rng.standard_normal((B, L, L)) * 3.0
+            logits[:, :, 1:] += a + a.transpose(0, 2, 1)
+        elif kind == 2:    # blocks of 3..5 words that point at each other, the root column unattractive
+            blk = rng.integers(3, 6)
+            same = (np.arange(L)[:, None] // blk) == (np.arange(L)[None, :] // blk)
+            logits[:, :, 1:] += 5.0 * same[None]
+            logits[:, :, 0] -= 3.0
+        elif kind == 3:    # several words that want the root
+            logits[:, :, 0] += rng.standard_normal((B, L)) * 4.0
+        e = np.exp(logits - logits.max(-1, keepdims=True))
+        yield (e / e.sum(-1, keepdims=True)).astype(np.float32), lens
+
+
+def test_mst_random_sweep_matches_oracle(dev):
+    """1152 sentences of 1..40 words in 24 batches of adversarial score patterns: every tree equal to the NumPy
+    restatement of the reference decoder (utils.py:400-577, pinned by G4), bit for bit."""
+    from oracle import cle_oracle
+    from cube_amd.networks.utils import ChuLiuEdmondsDecoder
+    dec = ChuLiuEdmondsDecoder(dev)
+    n = 0
+    for k, (probs, lens) in enumerate(_mst_sweep_batches()):
+        got = dec.decode(probs, lens)
+        exp = cle_oracle.decode(probs, lens)
+        for b in range(len(lens)):
+            np.testing.assert_array_equal(got[b], exp[b], err_msg="batch %d sentence %d (L=%d)" % (k, b, lens[b]))
+            n += 1
+    assert n == 24 * 48
+
+
 def test_mst_terminates_on_scores_that_are_not_probabilities(dev):
     """Negative, NaN and infinite "probabilities" (a caller's bug, an overwritten buffer): the contraction loop is the
     one data-dependent loop of the path, and it must end with a status for every sentence instead of spinning on a
