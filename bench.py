@@ -88,7 +88,8 @@ def build_model_and_batches(cfg_id, n_batches, rank, device, precision, ext=(300
     return p, cfg, enc, sd, batches, docs
 
 
-SETUP_STEPS = 48  # untimed passes before the warm-up steps (see main)
+TIMED_EVERY = int(os.environ.get("CUBE_BENCH_TIMED_EVERY", "5"))   # HIP events around every n-th char-conv launch of the timed region
+SETUP_STEPS = int(os.environ.get("CUBE_BENCH_SETUP_STEPS", "48"))  # untimed passes before the warm-up steps (see main)
 
 
 def run_steps(p, batches, n, serial=False):
@@ -272,12 +273,23 @@ def main():
     else:
         run_steps(p, batches, args.warmup)
         barrier()
-        p.start_kernel_timing("char_conv")
+        # live timing of the dominant kernel inside the timed region: every 5th of its launches (4 per step: the sample walks
+        # through the four layers), so that the measurement itself costs the region 0.3 % instead of 1.5 %
+        p.start_kernel_timing("char_conv", every=TIMED_EVERY)
         t0 = time.perf_counter()
         run_steps(p, batches, args.steps)
         barrier()
         dt = time.perf_counter() - t0
         kt = p.stop_kernel_timing()
+        # the same K steps twice more, each bracketed the same way: how far one box's timed regions scatter (`repeats`;
+        # `value` stays the FIRST region's figure)
+        repeat_dt = []
+        for _ in range(2 if args.steps <= 200 else 0):
+            barrier()
+            t1 = time.perf_counter()
+            run_steps(p, batches, args.steps)
+            barrier()
+            repeat_dt.append(time.perf_counter() - t1)
     # kernel-timing pass for the roofline: the same steps on ONE stream, so that the HIP events around a launch
     # bracket the kernel alone (in the pipelined region above they also bracket the time the launch waits for CUs
     # held by the other stages' kernels, and the kernel shares the chip with them while it runs)
@@ -290,10 +302,12 @@ def main():
         run_steps(p, batches, n_alone, serial=True)
         torch.cuda.synchronize()
         kt_alone = p.stop_kernel_timing()
+    if args.config == 3:
+        repeat_dt = []
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt] + repeat_dt, dtype=torch.float64, device=device)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, repeat_dt = float(t[0].item()), [float(x) for x in t[1:].tolist()]
     if rank != 0:
         if dist:
             td.destroy_process_group()
@@ -337,6 +351,7 @@ def main():
     achieved_region = flops_per_launch / (ms_region * 1e-3) / 1e12 if ms_region else 0.0
     roofline = dict(bound="mfma", achieved=achieved_region, peak=peak, unit="TFLOP/s",
                     frac=achieved_region / peak, traffic=traffic,
+                    timed_every=TIMED_EVERY if args.config != 3 else 1,
                     alone=dict(ms_per_launch=ms, achieved=achieved, frac=achieved / peak, launches=kt_alone["n"],
                                note="the same launches in a pass of the same steps on ONE stream inside this run: the kernel "
                                     "alone on the chip (rocprofv3 --kernel-trace of CUBE_BENCH_SERIAL=1 bench.py: "
@@ -354,7 +369,8 @@ def main():
                     frac_of_bf16_peak=achieved / BF16_DENSE_PEAK_TFLOPS,
                     kernel="gemm_kernel<GATE%s> (char conv, layers>=1)" % (", CfgI8, int8x2" if i8 else ""),
                     launches=kt["n"], ms_per_launch=ms_region,
-                    measured="HIP events around every launch of the kernel, on its stream, in the timed region",
+                    measured="HIP events around every `timed_every`-th launch of the kernel (the sample walks through its four layers), on "
+                             "its stream, in the timed region; `alone`: around every launch of the one-stream pass",
                     pipelined=dict(ms_per_launch=ms_pipelined, launches=kt["n"],
                                    achieved=flops_per_launch / (ms_pipelined * 1e-3) / 1e12 if ms_pipelined else 0.0,
                                    frac=flops_per_launch / (ms_pipelined * 1e-3) / 1e12 / peak if ms_pipelined else 0.0,
@@ -369,6 +385,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if args.config == 3 else "weak", "vs_baseline": None,
         # the default precision = the mode tests/test_gpu_parity.py holds to north_star's 99.9 % on the two full-size batches
+        # further regions of the same K steps in this run, same units as `value` (max over ranks each): the box's scatter
+        "repeats": [args.steps * c["B"] * world / x for x in repeat_dt] if args.config != 3 else [],
         "dtype": p.precision + ("+int8x2" if i8 else ""),
         "precision": dict(mode=p.precision, char_int8=bool(p.char_int8), word_int8=bool(p.word_int8), word0_int8=bool(p.word_int8 and p.word0_int8), lstm_int8=bool(p.lstm_int8),
                           what="bf16x3 = hi/lo bf16 planes, hi*hi + hi*lo + lo*hi on the matrix cores, fp32 accumulate; int8x2 = two "
