@@ -799,7 +799,7 @@ def test_config1_full_batch_matches_reference(dev, golden_dir):
     from cube_amd import synth
     from cube_amd.networks.utils import MorphoCollate
     p, cfg, enc, sd = _model(dev, cases.FULL, "bf16x3")
-    assert p.char_int8 and p.word_int8 and p.lstm_int8   # the fixed-point stages are on: this IS the benchmarked mode
+    assert p.char_int8 and p.word_int8 and p.lstm_int8 and not p.word0_int8   # the fixed-point stages are on: this IS the benchmarked mode
     g = np.load(os.path.join(golden_dir, "g11_bench_config1_256x32.npz"))
     doc = synth.make_document(enc, [32] * 256, seed=1000, ext_word_emb=(300,))
     r = p.decode_batch(MorphoCollate(enc).collate_fn(doc.sentences, targets=False))
@@ -1305,7 +1305,7 @@ def test_config2_full_size(dev, golden_dir):
     np.testing.assert_array_equal(rs["label_logits"].cpu().numpy(), lab[keep])
     # the WHOLE batch (8192 tokens: the 99.9 % bar needs that many) against the reference's own outputs for it (G11), in the
     # default precision = the mode `bench.py --config 2` reports
-    assert p.char_int8 and p.word_int8 and p.lstm_int8
+    assert p.char_int8 and p.word_int8 and p.lstm_int8 and not p.word0_int8
     r = p.decode_batch(X)
     torch.cuda.synchronize()
     g = np.load(os.path.join(golden_dir, "g11_bench_config2_64x128.npz"))
