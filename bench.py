@@ -241,6 +241,13 @@ def main():
     # pause run 4 % slower) -- so that the K timed steps measure the path, not the box's power state.  Reported as
     # config.setup_steps.
     setup_steps = max(len(batches), SETUP_STEPS) if args.config != 3 else len(batches)
+    # a generation-2 collection of the interpreter inside a 28 ms region would cost it tens of milliseconds (seen once in 15
+    # regions: 48k instead of 179k sentences/s): collect now and keep the collector off until the regions are over.  BEFORE
+    # the set-up steps: the collection takes ~0.1 s of host time with the GPU idle, and the first steps after such a pause
+    # run on the GPU's way back up from its idle clocks (collecting right before the timed region: 180k -> 167k)
+    import gc
+    gc.collect()
+    gc.disable()
     run_steps(p, batches, setup_steps)
     barrier()
     if args.config == 3:
@@ -290,6 +297,7 @@ def main():
             run_steps(p, batches, args.steps)
             barrier()
             repeat_dt.append(time.perf_counter() - t1)
+    gc.enable()
     # kernel-timing pass for the roofline: the same steps on ONE stream, so that the HIP events around a launch
     # bracket the kernel alone (in the pipelined region above they also bracket the time the launch waits for CUs
     # held by the other stages' kernels, and the kernel shares the chip with them while it runs)
