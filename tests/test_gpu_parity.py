@@ -852,6 +852,33 @@ def test_full_size_batch_properties(dev):
     _check_batch_against_oracle(p, rs, e, [32] * len(keep), min_agree=0.98)
 
 
+def test_full_size_batch_twice_and_permuted(dev):
+    """Two more size-independent properties on the bench workload (256 x 32, default precision): the same batch decoded
+    twice gives the same bits (no atomics, no order-dependent reductions anywhere on the path), and the same sentences in
+    another order give the same bits per sentence (the ragged character layouts regroup the words, the recurrence and the
+    decoder take other workgroups: a sentence's results may depend on neither)."""
+    from cube_amd import synth
+    from cube_amd.networks.utils import MorphoCollate
+    p, cfg, enc, sd = _model(dev, cases.FULL, "bf16x3")
+    doc = synth.make_document(enc, [32] * 256, seed=1002, ext_word_emb=(300,))
+    col = MorphoCollate(enc)
+    keys = ("arc_logits", "label_logits", "upos_logits", "heads", "labels", "upos")
+
+    def run(sents):
+        r = p.decode_batch(col.collate_fn(sents, targets=False))
+        assert (r["status"].cpu().numpy() == 0).all()
+        return {k: r[k].cpu().numpy().copy() for k in keys}
+
+    a = run(doc.sentences)
+    b = run(doc.sentences)
+    for k in keys:
+        np.testing.assert_array_equal(a[k], b[k], err_msg="second run: " + k)
+    perm = np.random.default_rng(3).permutation(256)
+    c = run([doc.sentences[i] for i in perm])
+    for k in keys:
+        np.testing.assert_array_equal(c[k], a[k][perm], err_msg="permuted batch: " + k)
+
+
 def test_process_edge_documents(dev):
     """Edge inputs of Parser.process: an empty document, one-word sentences only, and a document
     with a 150-word sentence next to short ones (MST long-sentence mode, heavy padding) — the
