@@ -74,6 +74,9 @@ constexpr int MAX_TAPS = 5;
 #ifndef CUBE_EPI_PREFETCH
 #define CUBE_EPI_PREFETCH 1
 #endif
+#ifndef CUBE_I8_AD
+#define CUBE_I8_AD 2  // units the int8x2 tile's activation fragments run ahead of their MFMAs (A/B: scripts/ab_build.py)
+#endif
 // -DCUBE_GEMM_PROF (scripts/ab_build.py + scripts/gemm_phase_prof.py): wall-clock stamps (10 ns units) per workgroup of the
 // int8x2 character-CNN tile -- entry, prologue done, k-loop done, end -- read back with cube_gemm_prof()
 #ifdef CUBE_GEMM_PROF
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64 * C::WM * C::WN) void gemm_kernel(const GemmPara
     // and two waves' reads queue in front of each other: two units ahead, and the second k-substep's
     // weight fragments right behind the first's (137.5k vs 135.5-137.1k sentences/s).  The same in the bf16
     // tiles: 133.3k (dropped).
-    constexpr int AD = I8 ? 2 : 1, AR = AD + 1;
+    constexpr int AD = I8 ? CUBE_I8_AD : 1, AR = AD + 1;
     frag_t fb[2][NP][TN];
     frag_t fa[AR][NP];
 #pragma unroll
