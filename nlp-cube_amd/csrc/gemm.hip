@@ -965,12 +965,19 @@ int gemm_entry(const cube_gemm_args* a, const float* w_scale, void* stream) {
       {  // h (and the bf16 copy of c) must not alias the columns of A that other workgroups still read
         const char* a0 = (const char*)a->A;
         const char* a1 = a0 + 2 * ((size_t)(a->M - 1) * a->lda + a->Kc);
-        const char* o0 = (const char*)a->out0 + 2 * (size_t)a->col0;
-        const char* o1 = o0 + 2 * ((size_t)(a->M - 1) * a->ldo0 + a->n_valid);
-        bool clash = o0 < a1 && a0 < o1 && a->lda == a->ldo0 &&
-                     ((o0 - a0) / 2 % a->lda) < (size_t)a->Kc;  // same row pitch: columns [col, col+units) against [0, Kc)
-        if (o0 < a1 && a0 < o1 && a->lda != a->ldo0) clash = true;
-        if (clash) CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue: out0 overlaps the columns of A this launch reads (use a second buffer)", fn);
+        auto clash = [&](const void* out, int col, int ld) {
+          if (!out) return false;
+          const char* o0 = (const char*)out + 2 * (size_t)col;
+          const char* o1 = o0 + 2 * ((size_t)(a->M - 1) * ld + a->n_valid);
+          if (!(o0 < a1 && a0 < o1)) return false;   // disjoint address ranges
+          if (ld != a->lda) return true;              // interleaved with another row pitch: refuse
+          const ptrdiff_t d = (o0 - a0) / 2;          // same pitch: the column range of the output against [0, Kc)
+          const ptrdiff_t c0 = ((d % ld) + ld) % ld;
+          return c0 < a->Kc || c0 + a->n_valid > ld;
+        };
+        if (clash(a->out0, a->col0, a->ldo0) || clash(a->out0_lo, a->col0, a->ldo0) || clash(a->out1, a->col1, a->ldo1) ||
+            clash(a->out1_lo, a->col1, a->ldo1))
+          CUBE_FAIL(CUBE_ERR_ARG, "%s: LSTM epilogue: out0 / out1 overlap the columns of A this launch reads (use a second buffer)", fn);
       }
       rc = launch<CUBE_EPI_LSTM>(p, cg, st);
       break;
