@@ -198,7 +198,9 @@ def stream_handle():
     """HIP stream of the CURRENT device.  Every launch path of a model runs under `on_device`, which makes
     the model's device current first: a stream of another device with this model's pointers would fault."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle straight from torch's C layer: torch.cuda.current_stream() builds a Stream object and resolves device
+    # indices in Python (~10 us; a small batch asks ~20 times)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def on_device(fn):
@@ -236,31 +238,34 @@ def gemm(A, lda, M, Kc, W, N, bias, epilogue, out0=None, ldo0=0, col0=0, taps=1,
     w_scale (f32 [N]): A, W and out0 are int8x2 planes (cube_gemm_i8x2; lda, Kc, ldo0 in int8 elements).
     out0_int8: bf16 operands, but out0 receives the gate values as int8x2 planes (ldo0 in int8 elements).
     batch > 1: that many same-shape Linear problems in one launch (strides in elements, see include/cube_hip.h)."""
-    a = GemmArgs()
-    a.A, a.A_lo = _planes(A, a_col)
-    a.W, a.W_lo = _planes(W)
-    if a.A_lo is None or a.W_lo is None:
-        a.A_lo = a.W_lo = None
-    a.lda, a.M, a.seq_len, a.taps, a.Kc = lda, M, seq_len, taps, Kc
-    a.N, a.bias = N, ptr(bias)
-    a.epilogue, a.n_valid, a.accumulate = epilogue, n_valid, accumulate
+    # one constructor call in field order (40 attribute stores on a ctypes structure cost more than the launch itself)
+    A_hi, A_lo = _planes(A, a_col)
+    W_hi, W_lo = _planes(W)
+    if A_lo is None or W_lo is None:
+        A_lo = W_lo = None
     if epilogue == EPI_F32:
-        a.out0, a.out0_lo = ptr(out0), None
+        o0, o0_lo = ptr(out0), None
     else:
-        a.out0, a.out0_lo = _planes(out0)
-    a.ldo0, a.col0 = ldo0, col0
-    a.rowmap = ptr(rowmap)
-    a.res, a.ld_res, a.res_mode = ptr(res), ld_res, res_mode
-    a.out1, a.out1_lo = _planes(out1)
-    a.ldo1, a.col1 = ldo1, col1
-    a.out2, a.out2_lo = _planes(out2)
-    a.ldo2, a.col2 = ldo2, col2
-    a.bias_tab, a.row_group = ptr(bias_tab), ptr(row_group)
-    a.n_groups = 0 if bias_tab is None else bias_tab.shape[0]
+        o0, o0_lo = _planes(out0)
+    o1, o1_lo = _planes(out1)
+    o2, o2_lo = _planes(out2)
+    a = GemmArgs(A_hi, A_lo, lda, M, seq_len, taps, Kc,
+                 W_hi, W_lo, N, ptr(bias),
+                 epilogue, n_valid, accumulate,
+                 o0, o0_lo, ldo0, col0,
+                 ptr(rowmap),
+                 ptr(res), ld_res, res_mode,
+                 o1, o1_lo, ldo1, col1,
+                 o2, o2_lo, ldo2, col2,
+                 ptr(bias_tab), ptr(row_group), 0 if bias_tab is None else bias_tab.shape[0])
     if groups is not None:
         a.groups = ctypes.pointer(groups)
-    a.out0_int8 = 1 if out0_int8 else 0
-    a.batch, a.stride_A, a.stride_W, a.stride_bias, a.stride_col0 = batch, stride_a, stride_w, stride_bias, stride_col0
+    if out0_int8:
+        a.out0_int8 = 1
+    if batch != 1:
+        a.batch, a.stride_A, a.stride_W, a.stride_bias, a.stride_col0 = batch, stride_a, stride_w, stride_bias, stride_col0
+    else:
+        a.batch = 1
     if w_scale is not None:
         if a_col or col0:
             raise ValueError("int8x2 operands start at column 0")

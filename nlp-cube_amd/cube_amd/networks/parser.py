@@ -34,6 +34,33 @@ from cube_amd.networks.utils import MorphoCollate, MorphoDataset, ChuLiuEdmondsD
 _STAGE_STREAMS = {}   # (device type, index) -> the three stage streams shared by all models on that device (_init_pipeline)
 
 
+class _TimedLaunch:
+    """HIP events around one launch on the current stream (`_HipNet.start_kernel_timing`)."""
+
+    def __init__(self, timing):
+        self.timing = timing
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.timing["pairs"].append((self.a, self.b))
+
+
+class _NoTiming:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMING = _NoTiming()
+
+
 class _Buffers:
     """Grow-only, zero-initialised flat device buffers with fixed leading dimensions, so the
     padding columns no kernel writes stay zero for the life of the model.  bf16 buffers are
@@ -181,25 +208,13 @@ class _HipNet:
                     ms_min=float(np.min(ms)) if ms else 0.0)
 
     def _timed(self, tag):
-        parser = self
-
-        class _Ctx:
-            def __enter__(self_):
-                t = parser._timing
-                self_.on = t is not None and t["tag"] == tag
-                if self_.on:
-                    t["seen"] += 1
-                    self_.on = (t["seen"] - 1) % t["every"] == 0
-                if self_.on:
-                    self_.a = torch.cuda.Event(enable_timing=True)
-                    self_.b = torch.cuda.Event(enable_timing=True)
-                    self_.a.record()
-
-            def __exit__(self_, *exc):
-                if self_.on:
-                    self_.b.record()
-                    parser._timing["pairs"].append((self_.a, self_.b))
-        return _Ctx()
+        t = self._timing
+        if t is None or t["tag"] != tag:
+            return _NO_TIMING
+        t["seen"] += 1
+        if (t["seen"] - 1) % t["every"]:
+            return _NO_TIMING
+        return _TimedLaunch(t)
 
     # ---- batch preparation -----------------------------------------------------------------
     _PART_NAMES = ("char_idx", "case_idx", "lang_word", "word_len", "rowmap_word", "word_idx", "lang_rows", "root_rows",
