@@ -36,3 +36,4 @@ p.process(doc, col)
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
